@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz + schema.json by running the imported REFERENCE on closed-form data.
+
+CONTAINER-ONLY: needs /root/reference (read-only mount) — it does not exist on the GPU box, where
+the committed fixtures are used instead.  Run from the repo root:  python tests/golden/make_golden.py
+
+What is pinned: schedule tables; per-module forward outputs + input/parameter
+gradients in train() and eval(); whole ContextUnet (F=16, 4 classes) at 64^2 (k=4) and 128^2 (k=8);
+DDPM.forward loss with the three random draws injected; DDPM.sample short trajectories with
+injected noise; the MNIST ancestor net.  Weights/inputs come from oracle.synth (closed form), so
+the fixtures hold outputs only, plus the key schema the reference's state_dict() exposes.
+
+Harness adjustments that are not behaviour changes: `local_enhance` inside the net is
+replaced by identity (the reference call is identically zero whenever it does not raise), and for
+64^2 the bottleneck AvgPool/ConvTranspose kernel 8 is swapped for 4.
+"""
+import json
+import os
+import sys
+from unittest import mock
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import _refload, synth  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(4)
+SCHEMA = {}
+
+
+def load_synth(mod, prefix=""):
+    sd = mod.state_dict()
+    new = {k: synth.synth_tensor(prefix + k, tuple(v.shape)) for k, v in sd.items()}
+    mod.load_state_dict(new, strict=True)
+    return [(k, list(v.shape)) for k, v in sd.items()]
+
+
+def run_module(name, mod, inputs, call=None, train_modes=(False, True)):
+    """inputs: dict name->tensor (float ones get requires_grad).  Saves y, input grads, param grads,
+    and BN running stats after the train-mode forward."""
+    SCHEMA[name] = load_synth(mod)
+    init = {k: v.clone() for k, v in mod.state_dict().items()}
+    out = {}
+    for train in train_modes:
+        mod.load_state_dict(init)
+        mod.train(train)
+        tag = "train" if train else "eval"
+        ins = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.startswith("mask") else v)
+               for k, v in inputs.items()}
+        y = call(mod, ins) if call else mod(*ins.values())
+        probe = synth.synth_input(name + ".probe", tuple(y.shape))
+        mod.zero_grad()
+        (y * probe).sum().backward()
+        out[f"{tag}.y"] = y.detach().numpy()
+        for k, v in ins.items():
+            if v.is_floating_point() and v.grad is not None:
+                out[f"{tag}.d_{k}"] = v.grad.numpy()
+        for k, p in mod.named_parameters():
+            out[f"{tag}.g.{k}"] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+        if train:
+            for k, b in mod.named_buffers():
+                if "running" in k:
+                    out[f"train.buf.{k}"] = b.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, {k: v.shape for k, v in list(out.items())[:3]})
+
+
+def gen_schedules(R):
+    out = {}
+    for T in (400, 700, 1000):
+        for k, v in R.ddpm_schedules(1e-4, 0.02, T).items():
+            out[f"T{T}.{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "schedules.npz"), **out)
+
+
+def gen_modules(R):
+    si = synth.synth_input
+    run_module("se32", R.SEBlock(32), {"x": si("se32.x", (2, 32, 8, 8))})
+    run_module("ca32_8", R.CoordAttn(32), {"x": si("ca32_8.x", (3, 32, 8, 8))})
+    run_module("ca32_16", R.CoordAttn(32), {"x": si("ca32_16.x", (2, 32, 16, 16))})
+    run_module("rcb_3_16_res", R.ResConvBlock(3, 16, True), {"x": si("rcb_3_16_res.x", (2, 3, 16, 16))})
+    run_module("rcb_16_16_res", R.ResConvBlock(16, 16, True), {"x": si("rcb_16_16_res.x", (2, 16, 16, 16))})
+    run_module("rcb_16_16_plain", R.ResConvBlock(16, 16, False), {"x": si("rcb_16_16_plain.x", (2, 16, 16, 16))})
+    run_module("down_16_32", R.UnetDown(16, 32), {"x": si("down_16_32.x", (2, 16, 16, 16))})
+    run_module("up_64_16", R.UnetUp(64, 16), {"x": si("up_64_16.x", (2, 32, 8, 8)), "skip": si("up_64_16.skip", (2, 32, 8, 8))})
+    run_module("fc_1_32", R.EmbedFC(1, 32), {"x": si("fc_1_32.x", (5, 1))})
+    run_module("fc_4_32", R.EmbedFC(4, 32), {"x": si("fc_4_32.x", (5, 4))})
+    m = synth.synth_attn_mask(2, 16)
+    run_module("le16", R.LocalEnhancer(16), {"x": si("le16.x", (2, 16, 16, 16)), "mask": m})
+
+
+def make_ref_unet(R, nf, ncls, k):
+    net = R.ContextUnet(3, nf, ncls)
+    net.local_enhance.forward = lambda x, mask: x
+    if k != 8:
+        net.to_vec[0] = torch.nn.AvgPool2d(k)
+        net.up0[0] = torch.nn.ConvTranspose2d(8 * nf, 8 * nf, k, k)
+    return net
+
+
+def child_grad_norms(net):
+    d = {}
+    for cname, child in net.named_children():
+        sq = sum(float((p.grad.double() ** 2).sum()) for p in child.parameters() if p.grad is not None)
+        d[cname] = sq ** 0.5
+    return d
+
+
+def gen_unet(R, tag, S, k, nf=16, ncls=4, B=2):
+    net = make_ref_unet(R, nf, ncls, k)
+    SCHEMA[tag] = load_synth(net)
+    init = {kk: v.clone() for kk, v in net.state_dict().items()}
+    x = synth.synth_input(tag + ".x", (B, 3, S, S))
+    c = torch.tensor([(3 * i + 1) % ncls for i in range(B)])
+    t = torch.tensor([(0.37 + 0.41 * i) % 1.0 for i in range(B)])
+    mk = torch.tensor([float((i + 1) % 2) for i in range(B)])
+    out = {"c": c.numpy(), "t": t.numpy(), "ctx_mask": mk.numpy()}
+    for train in (False, True):
+        net.load_state_dict(init)
+        net.train(train)
+        mode = "train" if train else "eval"
+        xx = x.clone().requires_grad_(True)
+        eps = net(xx, c, t, mk)
+        probe = synth.synth_input(tag + ".probe", tuple(eps.shape))
+        net.zero_grad()
+        loss = (eps * probe).mean()
+        loss.backward()
+        out[f"{mode}.eps"] = eps.detach().numpy()
+        out[f"{mode}.loss"] = np.float64(loss.item())
+        out[f"{mode}.dx"] = xx.grad.numpy()
+        for cn, v in child_grad_norms(net).items():
+            out[f"{mode}.gn.{cn}"] = np.float64(v)
+        for pn in ("out.3.weight", "init_conv.conv1.0.weight", "ca2.gamma_h", "ca1.alpha", "down1.ch_adjust.weight",
+                   "time_emb2.model.0.weight", "up0.1.weight", "down2.down.3.se.fc.0.weight", "ctx_emb1.model.2.bias"):
+            out[f"{mode}.g.{pn}"] = dict(net.named_parameters())[pn].grad.numpy()
+        # the same reference code run in float64: separates rounding noise from real differences
+        net.load_state_dict(init)
+        net.double()
+        with torch.no_grad():
+            out[f"{mode}.eps64"] = net(x.double(), c, t.double(), mk.double()).numpy()
+        net.float()
+        net.load_state_dict(init)
+        if train:
+            net(x, c, t, mk)   # redo the fp32 train forward so the running stats below are the fp32 ones
+            for bn in ("init_conv.conv1.1.running_mean", "init_conv.conv1.1.running_var",
+                       "ca3.bn1_h.running_var", "up4.model.2.conv2.1.running_mean"):
+                out[f"train.buf.{bn}"] = net.state_dict()[bn].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **out)
+    print(tag, out["eval.eps"].shape, out["eval.loss"], out["train.loss"], "fp32-vs-fp64 noise eval/train:",
+          np.abs(out["eval.eps"] - out["eval.eps64"]).max(), np.abs(out["train.eps"] - out["train.eps64"]).max())
+
+
+class Inject:
+    """Replace the reference's three RNG draws (new_scripy.py:405,406,413 / 445,465) by closed-form data."""
+
+    def __init__(self, tag, n_T):
+        self.tag, self.n_T, self.n = tag, n_T, 0
+
+    def randint(self, lo, hi, shape, **kw):
+        return torch.tensor([(lo + (313 * i + 96) % (hi - lo)) for i in range(shape[0])])
+
+    def randn_like(self, x, **kw):
+        return synth.synth_noise(self.tag + ".noise", tuple(x.shape))
+
+    def bernoulli(self, p, **kw):
+        return torch.tensor([float((i % 3) != 1) for i in range(p.shape[0])])
+
+    def randn(self, *shape, **kw):
+        self.n += 1
+        return synth.synth_noise(f"{self.tag}.z{self.n - 1}", tuple(shape))
+
+
+def gen_ddpm_forward(R, tag="ddpm_fwd64", S=64, k=4, nf=16, ncls=4, B=4, n_T=1000):
+    net = make_ref_unet(R, nf, ncls, k)
+    ddpm = R.DDPM(net, (1e-4, 0.02), n_T, "cpu", drop_prob=0.1)
+    SCHEMA[tag] = load_synth(ddpm)   # includes the 7 schedule buffers -> overwritten by synth! restore:
+    for kk, v in R.ddpm_schedules(1e-4, 0.02, n_T).items():
+        getattr(ddpm, kk).copy_(v)
+    x = synth.synth_input(tag + ".x", (B, 3, S, S))
+    c = torch.tensor([(i + 2) % ncls for i in range(B)])
+    am = synth.synth_attn_mask(B, S)
+    inj = Inject(tag, n_T)
+    out = {}
+    init = {kk: v.clone() for kk, v in ddpm.state_dict().items()}
+    for train in (True, False):
+        ddpm.load_state_dict(init)
+        ddpm.train(train)
+        ddpm.zero_grad()
+        with mock.patch.object(torch, "randint", inj.randint), mock.patch.object(torch, "randn_like", inj.randn_like), \
+                mock.patch.object(torch, "bernoulli", inj.bernoulli):
+            loss = ddpm(x, c, am)
+        mode = "train" if train else "eval"
+        out[f"{mode}.loss"] = np.float64(loss.item())
+        if train:
+            loss.backward()
+            for cn, v in child_grad_norms(ddpm.nn_model).items():
+                out[f"train.gn.{cn}"] = np.float64(v)
+            out["train.g.out.3.weight"] = ddpm.nn_model.out[3].weight.grad.numpy()
+    out["ts"] = inj.randint(1, n_T + 1, (B,)).numpy()
+    out["keep"] = inj.bernoulli(torch.ones(B)).numpy()
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **out)
+    print(tag, out['train.loss'], out['eval.loss'], out['ts'])
+
+
+def gen_ddpm_sample(R, tag, S, k, n_T, n, guide_w, nf=16, ncls=4):
+    net = make_ref_unet(R, nf, ncls, k)
+    ddpm = R.DDPM(net, (1e-4, 0.02), n_T, "cpu", drop_prob=0.0)
+    load_synth(ddpm)
+    for kk, v in R.ddpm_schedules(1e-4, 0.02, n_T).items():
+        getattr(ddpm, kk).copy_(v)
+    ddpm.eval()
+    inj = Inject(tag, n_T)
+    with torch.no_grad(), mock.patch.object(torch, "randn", inj.randn):
+        x = ddpm.sample(n, (3, S, S), "cpu", guide_w=guide_w)
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), x=x.numpy(), n_draws=np.int64(inj.n))
+    print(tag, x.shape, float(x.abs().max()), inj.n)
+
+
+def gen_mnist(M):
+    nf, ncls = 16, 10
+    net = M.ContextUnet(1, nf, ncls)
+    SCHEMA["mnist16"] = load_synth(net)
+    init = {k: v.clone() for k, v in net.state_dict().items()}
+    B = 3
+    x = synth.synth_input("mnist16.x", (B, 1, 28, 28))
+    c = torch.tensor([1, 7, 4])
+    t = torch.tensor([0.2, 0.55, 0.9])
+    mk = torch.tensor([0.0, 1.0, 0.0])
+    out = {}
+    for train in (False, True):
+        net.load_state_dict(init)
+        net.train(train)
+        mode = "train" if train else "eval"
+        eps = net(x, c, t, mk)
+        probe = synth.synth_input("mnist16.probe", tuple(eps.shape))
+        net.zero_grad()
+        (eps * probe).mean().backward()
+        out[f"{mode}.eps"] = eps.detach().numpy()
+        for cn, v in child_grad_norms(net).items():
+            out[f"{mode}.gn.{cn}"] = np.float64(v)
+    # DDPM.forward (plain MSE, MNIST_script.py:234-252) with injected draws
+    net.load_state_dict(init)
+    ddpm = M.DDPM(net, (1e-4, 0.02), 400, "cpu", drop_prob=0.1)
+    inj = Inject("mnist16", 400)
+    ddpm.train()
+    with mock.patch.object(torch, "randint", inj.randint), mock.patch.object(torch, "randn_like", inj.randn_like), \
+            mock.patch.object(torch, "bernoulli", lambda p, **kw: torch.tensor([float(i % 3 == 1) for i in range(p.shape[0])])):
+        loss = ddpm(x, c)
+    out["ddpm.loss"] = np.float64(loss.item())
+    # sample: 4 steps, n=10 (labels are hard-coded arange(0,10), MNIST_script.py:262)
+    net.load_state_dict(init)
+    d2 = M.DDPM(net, (1e-4, 0.02), 4, "cpu", drop_prob=0.1)
+    d2.eval()
+    inj = Inject("mnist16.s", 4)
+    with torch.no_grad(), mock.patch.object(torch, "randn", inj.randn):
+        xs, store = d2.sample(10, (1, 28, 28), "cpu", guide_w=0.5)
+    out["sample.x"] = xs.numpy()
+    out["sample.store_shape"] = np.array(store.shape)
+    np.savez_compressed(os.path.join(OUT, "mnist16.npz"), **out)
+    print("mnist16", out["eval.eps"].shape, out["ddpm.loss"])
+
+
+def main():
+    assert _refload.available(), "reference not mounted; fixtures are generated in the authoring container only"
+    R = _refload.load("new_scripy")
+    M = _refload.load("MNIST_script")
+    gen_schedules(R)
+    gen_modules(R)
+    gen_unet(R, "unet16_64", 64, 4)
+    gen_unet(R, "unet16_128", 128, 8)
+    gen_ddpm_forward(R)
+    gen_ddpm_sample(R, "sample64_T5", 64, 4, 5, 4, 2.0)
+    gen_ddpm_sample(R, "sample64_T3_w0", 64, 4, 3, 8, 0.0)
+    gen_mnist(M)
+    # key schema of the full-size nets (shapes only; no tensors are instantiated for the big ones)
+    SCHEMA["ddpm_keys_F16_k4"] = [(k, list(v.shape)) for k, v in
+                                  R.DDPM(make_ref_unet(R, 16, 4, 4), (1e-4, 0.02), 1000, "cpu").state_dict().items()]
+    SCHEMA["unet_keys_F32_k8_c10"] = [(k, list(v.shape)) for k, v in R.ContextUnet(3, 32, 10).state_dict().items()]
+    SCHEMA["mnist_keys_F32"] = [(k, list(v.shape)) for k, v in M.ContextUnet(1, 32, 10).state_dict().items()]
+    SCHEMA["cfg"] = {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(R.Cfg).items() if k.isupper()}
+    with open(os.path.join(OUT, "schema.json"), "w") as f:
+        json.dump(SCHEMA, f, indent=0)
+    sz = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("total fixture bytes", sz)
+
+
+if __name__ == "__main__":
+    main()
