@@ -1,0 +1,153 @@
+"""ctypes binding of libdm_amd.so (include/dm_amd.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, an exception is
+raised.  Tensors cross the boundary as raw device pointers (`tensor.data_ptr()`), sizes as plain
+ints, and every launch goes to torch's current HIP stream, so calls are capturable in a hipGraph.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdm_amd.so")
+
+DM_F32, DM_BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+
+vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+
+
+class DmConv(C.Structure):
+    _fields_ = [(n, vp) for n in ("in1", "in2", "w", "scale", "shift", "out", "psum", "psq")] + [
+        (n, i32) for n in ("dtype", "act", "out_nchw_f32", "B", "Hi", "Wi", "C1", "C2", "Hq", "Wq", "sy", "sx", "T", "KW",
+                           "ty", "tx", "oy0", "ox0", "Ho", "Wo", "osy", "osx", "ooy", "oox", "N", "ldw", "ldc", "coff")]
+
+
+class DmWgrad(C.Structure):
+    _fields_ = [(n, vp) for n in ("dy", "in1", "in2", "dw", "dbias")] + [
+        (n, i32) for n in ("dtype", "B", "Hi", "Wi", "C1", "C2", "Hq", "Wq", "sy", "sx", "T", "KW", "ty", "tx", "oy0", "ox0",
+                           "Ho", "Wo", "osy", "osx", "ooy", "oox", "N", "ldy", "ldw", "splitk")]
+
+
+# name -> argument ctypes (the trailing dm_stream_t is appended automatically unless noted)
+_PROTOS = {
+    "dm_conv": [C.POINTER(DmConv)],
+    "dm_conv_wgrad": [C.POINTER(DmWgrad)],
+    "dm_pack_w": [vp, vp, i32, i32, i32, i32, i32],
+    "dm_pack_wT": [vp, vp, i32, i32, i32, i32, i32, C.POINTER(i32), i32],
+    "dm_unpad_dw": [vp, vp, i32, i32, i32, i32, i32],
+    "dm_col_stats": [vp, i32, i32, i32, vp, vp],
+    "dm_bn_finalize": [vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp],
+    "dm_bn_act_fwd": [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32],
+    "dm_bn_act_bwd_reduce": [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp],
+    "dm_col_reduce": [vp, i32, i32, vp, i32],
+    "dm_bn_act_bwd_apply": [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp],
+    "dm_bn_fold": [vp, vp, vp, vp, vp, f32, i32, vp, vp],
+    "dm_gn_act_fwd": [vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp],
+    "dm_gn_act_bwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp],
+    "dm_pool_hw": [vp, i32, i32, i32, i32, vp],
+    "dm_scale_residual_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, f32],
+    "dm_scale_residual_bwd_reduce": [vp, vp, i32, i32, i32, i32, f32, vp],
+    "dm_scale_residual_bwd_apply": [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32],
+    "dm_ca_pool_fwd": [vp, i32, i32, i32, i32, i32, vp, vp],
+    "dm_ca_pool_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32],
+    "dm_ca_gate_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32],
+    "dm_ca_gate_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32],
+    "dm_sigmix_fwd": [vp, vp, vp, vp, i32],
+    "dm_sigmix_bwd": [vp, vp, vp, vp, vp, i32],
+    "dm_linear_fwd": [vp, vp, vp, vp, i32, i32, i32, i32],
+    "dm_linear_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32],
+    "dm_act_fwd": [vp, vp, i32, i32],
+    "dm_act_bwd": [vp, vp, vp, i32, i32],
+    "dm_onehot_mask": [vp, vp, vp, i32, i32, i32],
+    "dm_nchw_to_nhwc": [vp, vp, i32, i32, i32, i32, i32, i32, i32],
+    "dm_nhwc_to_nchw": [vp, vp, i32, i32, i32, i32, i32, i32],
+    "dm_cast": [vp, vp, i32, i32, i64],
+    "dm_film_fwd": [vp, vp, vp, vp, i32, i32, i32, i32],
+    "dm_film_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32],
+    "dm_upcat_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32],
+    "dm_upcat_bwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32],
+    "dm_cat_fwd": [vp, vp, vp, i32, i32, i32, i32],
+    "dm_cat_bwd": [vp, vp, vp, i32, i32, i32, i32],
+    "dm_avgpool_gelu_fwd": [vp, vp, i32, i32, i32, i32, i32, i32],
+    "dm_avgpool_gelu_bwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32],
+    "dm_maxpool2_fwd": [vp, vp, i32, i32, i32, i32, i32],
+    "dm_maxpool2_bwd": [vp, vp, vp, i32, i32, i32, i32, i32],
+    "dm_add": [vp, vp, vp, i32, i64],
+    "dm_qsample": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32],
+    "dm_loss_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32],
+    "dm_loss_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32],
+    "dm_cfg_update": [vp, vp, vp, f32, vp, vp, vp, vp, u64, i64, i32],
+    "dm_fill_t": [vp, vp, i32, i32],
+    "dm_randn": [vp, i64, u64, u64],
+    "dm_sumsq": [vp, i64, vp],
+    "dm_adamw": [vp, vp, vp, vp, i64, vp, vp],
+}
+_NO_STREAM = {"dm_version": ([], i32), "dm_last_error": ([], C.c_char_p), "dm_colstat_blocks": ([i32], i32)}
+
+EXPORTED = sorted(list(_PROTOS) + list(_NO_STREAM))
+
+_lib = None
+
+
+class DmError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdm_amd.so (once).  Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise DmError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(or `make -C diffusionmodel_amd/csrc`). diffusionmodel_amd has no CPU/ATen fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = list(args) + [vp]
+        fn.restype = i32
+    for name, (args, res) in _NO_STREAM.items():
+        fn = getattr(lib, name)
+        fn.argtypes = list(args)
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def dt(t_or_dtype):
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    if d == torch.float32:
+        return DM_F32
+    if d == torch.bfloat16:
+        return DM_BF16
+    raise DmError(f"unsupported dtype {d}: the HIP path computes in float32 or bfloat16")
+
+
+def call(name, *args):
+    """Invoke an entry point on the current stream; raise DmError on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args, _stream())
+    if rc != 0:
+        raise DmError(f"{name} failed (rc={rc}): {lib.dm_last_error().decode()}")
+
+
+def colstat_blocks(m):
+    return load().dm_colstat_blocks(int(m))
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise DmError("diffusionmodel_amd runs on a HIP device only (got a CPU tensor). "
+                          "There is deliberately no CPU fallback; the CPU restatement lives in oracle/ for tests.")

@@ -1,0 +1,407 @@
+// Channel-attention pieces: SE squeeze/scale + residual combine, coordinate-attention strip pooling and
+// gated multiply, and the small fp32 dense layers (EmbedFC, SE fc, CoordAttn 1x1 convs on strips).
+// Activation tensors are NHWC `dtype`; strips, gates and embeddings are fp32.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// strip mean / product-sum: out[b,a,c] = scale * sum_r f(x[b, a*sa + r*sr, c])   (pixel-unit strides)
+// grid: B*A blocks; thread (cv, rl) with V channels; LDS folds the row lanes.
+// MODE 0: sum x ; MODE 1: sum x*y (second tensor same layout)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int V, int MODE>
+__global__ __launch_bounds__(256) void strip_reduce_kernel(const T* x, const T* y, float* out, int A, int R, int sa, int sr,
+                                                           int P /*pixels per sample*/, int C, float scale) {
+    __shared__ float red[2048];
+    const int b = blockIdx.x / A, a = blockIdx.x - b * A;
+    const int CVt = (C + V - 1) / V;
+    const size_t base = ((size_t)b * P + (size_t)a * sa) * C;
+    for (int cbase = 0; cbase < CVt; cbase += 256) {
+        const int ncv = min(256, CVt - cbase);
+        const int RL = 256 / ncv;
+        const int cv = threadIdx.x % ncv, rl = threadIdx.x / ncv;
+        float acc[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] = 0.f;
+        if (rl < RL) {
+            const int c0 = (cbase + cv) * V;
+            for (int r = rl; r < R; r += RL) {
+                float v[V];
+                const size_t off = base + (size_t)r * sr * C + c0;
+                if constexpr (V == 1) v[0] = Elem<T>::ld(x + off); else load_vec<T>(x + off, v);
+                if constexpr (MODE == 1) {
+                    float w[V];
+                    if constexpr (V == 1) w[0] = Elem<T>::ld(y + off); else load_vec<T>(y + off, w);
+#pragma unroll
+                    for (int i = 0; i < V; ++i) v[i] *= w[i];
+                }
+#pragma unroll
+                for (int i = 0; i < V; ++i) acc[i] += v[i];
+            }
+        }
+        __syncthreads();
+        if (rl < RL) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) red[(rl * ncv + cv) * V + i] = acc[i];
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < ncv * V; j += 256) {
+            float s = 0.f;
+            for (int l = 0; l < RL; ++l) s += red[l * ncv * V + j];
+            const int col = cbase * V + j;
+            if (col < C) out[((size_t)b * A + a) * C + col] = s * scale;
+        }
+        __syncthreads();
+    }
+}
+
+template <int MODE>
+int launch_strip(const void* x, const void* y, float* out, int dtype, int B, int A, int R, int sa, int sr, int P, int C, float scale,
+                 hipStream_t st) {
+    DM_DISPATCH_DTYPE(dtype, {
+        const uintptr_t m = (uintptr_t)x | (uintptr_t)y;
+        if (C % Elem<T>::VE == 0 && (m & 15) == 0)
+            hipLaunchKernelGGL((strip_reduce_kernel<T, Elem<T>::VE, MODE>), dim3(B * A), dim3(256), 0, st, (const T*)x, (const T*)y, out, A, R, sa, sr, P, C, scale);
+        else
+            hipLaunchKernelGGL((strip_reduce_kernel<T, 1, MODE>), dim3(B * A), dim3(256), 0, st, (const T*)x, (const T*)y, out, A, R, sa, sr, P, C, scale);
+    });
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+// out = (res + x2 * s[b,c]) * inv
+template <typename T>
+__global__ void scale_res_fwd_kernel(const T* x2, const T* res, const float* sg, T* out, int B, int HW, int C, float inv) {
+    const int64_t total = (int64_t)B * HW * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int b = (int)(i / ((int64_t)HW * C));
+        const float s = sg ? sg[b * C + c] : 1.f;
+        Elem<T>::st(out + i, (Elem<T>::ld(res + i) + Elem<T>::ld(x2 + i) * s) * inv);
+    }
+}
+// dx2 = dout*inv*s + dym[b,c]/HW ; dres = dout*inv
+template <typename T>
+__global__ void scale_res_bwd_kernel(const T* dout, const float* sg, const float* dym, T* dx2, T* dres, int B, int HW, int C, float inv) {
+    const int64_t total = (int64_t)B * HW * C;
+    const float ihw = 1.f / (float)HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int b = (int)(i / ((int64_t)HW * C));
+        const float g = Elem<T>::ld(dout + i) * inv;
+        const float s = sg ? sg[b * C + c] : 1.f;
+        Elem<T>::st(dx2 + i, g * s + (dym ? dym[b * C + c] * ihw : 0.f));
+        Elem<T>::st(dres + i, g);
+    }
+}
+
+// ---- coordinate attention gate ------------------------------------------------------------------
+__device__ inline void ca_mix(const float* alpha, const float* beta, float& al, float& be) {
+    const float sa = sigmoid_f(alpha[0]), sb = sigmoid_f(beta[0]);
+    const float S = sa + sb + 1e-8f;
+    al = sa / S;
+    be = sb / S;
+}
+
+template <typename T>
+__global__ void ca_gate_fwd_kernel(const T* x, const float* lh, const float* lw, const float* alpha, const float* beta, T* out,
+                                   int B, int H, int W, int C) {
+    float al, be;
+    ca_mix(alpha, beta, al, be);
+    const int64_t total = (int64_t)B * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        int64_t r = i / C;
+        const int xx = (int)(r % W); r /= W;
+        const int yy = (int)(r % H);
+        const int b = (int)(r / H);
+        const float att = al * sigmoid_f(lh[((size_t)b * H + yy) * C + c]) + be * sigmoid_f(lw[((size_t)b * W + xx) * C + c]);
+        Elem<T>::st(out + i, Elem<T>::ld(x + i) * att);
+    }
+}
+
+// dx_gate = dout * att
+template <typename T>
+__global__ void ca_gate_bwd_dx_kernel(const T* dout, const float* lh, const float* lw, const float* alpha, const float* beta,
+                                      T* dx, int B, int H, int W, int C) {
+    float al, be;
+    ca_mix(alpha, beta, al, be);
+    const int64_t total = (int64_t)B * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        int64_t r = i / C;
+        const int xx = (int)(r % W); r /= W;
+        const int yy = (int)(r % H);
+        const int b = (int)(r / H);
+        const float att = al * sigmoid_f(lh[((size_t)b * H + yy) * C + c]) + be * sigmoid_f(lw[((size_t)b * W + xx) * C + c]);
+        Elem<T>::st(dx + i, Elem<T>::ld(dout + i) * att);
+    }
+}
+
+// strip sums S[b,a,c] = sum_r dout*x  ->  dl = mix * sig'(l) * S ;  dmix += sum sig(l) * S
+__global__ void ca_gate_bwd_strip_kernel(const float* S, const float* l, const float* alpha, const float* beta, int which,
+                                         float* dl, float* dmix, int64_t n) {
+    __shared__ float red[16];
+    float al, be;
+    ca_mix(alpha, beta, al, be);
+    const float mix = which == 0 ? al : be;
+    float part = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float sg = sigmoid_f(l[i]);
+        dl[i] = mix * sg * (1.f - sg) * S[i];
+        part += sg * S[i];
+    }
+    part = block_sum(part, red);
+    if (threadIdx.x == 0) atomicAdd(dmix + which, part);
+}
+
+// dmix = {d_al, d_be} -> out[0] = dalpha, out[1] = dbeta  (out += )
+__global__ void ca_mix_bwd_kernel(const float* alpha, const float* beta, const float* dmix, float* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float sa = sigmoid_f(alpha[0]), sb = sigmoid_f(beta[0]);
+    const float S = sa + sb + 1e-8f;
+    const float dsa = (dmix[0] * (S - sa) - dmix[1] * sb) / (S * S);
+    const float dsb = (dmix[1] * (S - sb) - dmix[0] * sa) / (S * S);
+    out[0] += dsa * sa * (1.f - sa);
+    out[1] += dsb * sb * (1.f - sb);
+}
+
+// dx = dgate + dxh[b,y,c]/W + dxw[b,x,c]/H
+template <typename T>
+__global__ void ca_pool_bwd_kernel(const float* dxh, const float* dxw, const T* dg, T* dx, int B, int H, int W, int C) {
+    const int64_t total = (int64_t)B * H * W * C;
+    const float iw = 1.f / (float)W, ih = 1.f / (float)H;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        int64_t r = i / C;
+        const int xx = (int)(r % W); r /= W;
+        const int yy = (int)(r % H);
+        const int b = (int)(r / H);
+        Elem<T>::st(dx + i, (dg ? Elem<T>::ld(dg + i) : 0.f) + dxh[((size_t)b * H + yy) * C + c] * iw + dxw[((size_t)b * W + xx) * C + c] * ih);
+    }
+}
+
+__global__ void sigmix_fwd_kernel(const float* x, const float* y, const float* gamma, float* xo, int n) {
+    const float sg = sigmoid_f(gamma[0]);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) xo[i] = x[i] + sg * y[i];
+}
+__global__ void sigmix_bwd_kernel(const float* dxo, const float* y, const float* gamma, float* dy, float* dgamma, int n) {
+    __shared__ float red[16];
+    const float sg = sigmoid_f(gamma[0]);
+    float part = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        dy[i] = sg * dxo[i];
+        part += dxo[i] * y[i];
+    }
+    part = block_sum(part, red);
+    if (threadIdx.x == 0) atomicAdd(dgamma, part * sg * (1.f - sg));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small fp32 GEMM with arbitrary strides: Cm[m][n] (+)= act(sum_k A(m,k) * Bm(k,n) + bias[n])
+// 64x64 tile, BK 16, 256 threads, 4x4 outputs per thread.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgemm_kernel(const float* A, const float* Bm, const float* bias, float* Cm, int M, int N, int K,
+                                                    int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int ldc, int act, int accumulate) {
+    __shared__ float sA[16][65], sB[16][65];
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = threadIdx.x + 256 * q;  // 0..1023 over 64 x 16
+            // choose the faster-varying index to follow the unit stride
+            int mi, ki;
+            if (sak == 1) { ki = idx & 15; mi = idx >> 4; } else { mi = idx & 63; ki = idx >> 6; }
+            const int m = m0 + mi, k = k0 + ki;
+            sA[ki][mi] = (m < M && k < K) ? A[m * sam + k * sak] : 0.f;
+            int ni, kj;
+            if (sbk == 1) { kj = idx & 15; ni = idx >> 4; } else { ni = idx & 63; kj = idx >> 6; }
+            const int n = n0 + ni, kk = k0 + kj;
+            sB[kj][ni] = (n < N && kk < K) ? Bm[kk * sbk + n * sbn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = sA[k][ty * 4 + i]; b[i] = sB[k][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty * 4 + i;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            if (n >= N) continue;
+            float v = acc[i][j] + (bias ? bias[n] : 0.f);
+            v = act_apply(v, act);
+            float* o = Cm + (size_t)m * ldc + n;
+            *o = accumulate ? *o + v : v;
+        }
+    }
+}
+
+__global__ void colsum_small_kernel(const float* dy, float* db, int M, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += dy[(size_t)m * N + n];
+    db[n] += s;
+}
+
+__global__ void act_fwd_kernel(const float* x, float* y, int n, int act) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) y[i] = act_apply(x[i], act);
+}
+__global__ void act_bwd_kernel(const float* x, const float* dy, float* dx, int n, int act) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dx[i] = dy[i] * act_grad(x[i], act);
+}
+
+__global__ void onehot_mask_kernel(const int64_t* c, const float* mask, float* out, int B, int ncls, int flip) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * ncls) return;
+    const int b = i / ncls, k = i - b * ncls;
+    const float m = flip ? -(1.f - mask[b]) : mask[b];
+    out[i] = (c[b] == (int64_t)k) ? m : 0.f * m;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)s)
+
+extern "C" int dm_pool_hw(const void* x, int dtype, int B, int HW, int C, float* mean_bc, dm_stream_t s) {
+    DM_CHECK_ARG(x && mean_bc && B > 0 && HW > 0 && C > 0, "dm_pool_hw: bad arguments");
+    return launch_strip<0>(x, nullptr, mean_bc, dtype, B, 1, HW, 0, 1, HW, C, 1.f / (float)HW, ST);
+}
+
+extern "C" int dm_scale_residual_fwd(const void* x2, const void* res, const float* sgate, void* out, int dtype, int B, int HW, int C,
+                                     float inv, dm_stream_t s) {
+    DM_CHECK_ARG(x2 && res && out && B > 0 && HW > 0 && C > 0, "dm_scale_residual_fwd: bad arguments");
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((scale_res_fwd_kernel<T>), dim3(grid_for((int64_t)B * HW * C, 256)), dim3(256), 0, ST, (const T*)x2, (const T*)res, sgate, (T*)out, B, HW, C, inv));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_scale_residual_bwd_reduce(const void* dout, const void* x2, int dtype, int B, int HW, int C, float inv, float* dsgate,
+                                            dm_stream_t s) {
+    DM_CHECK_ARG(dout && x2 && dsgate && B > 0 && HW > 0 && C > 0, "dm_scale_residual_bwd_reduce: bad arguments");
+    return launch_strip<1>(dout, x2, dsgate, dtype, B, 1, HW, 0, 1, HW, C, inv, ST);
+}
+
+extern "C" int dm_scale_residual_bwd_apply(const void* dout, const float* sgate, const float* dy_mean, void* dx2, void* dres, int dtype,
+                                           int B, int HW, int C, float inv, dm_stream_t s) {
+    DM_CHECK_ARG(dout && dx2 && dres && B > 0 && HW > 0 && C > 0, "dm_scale_residual_bwd_apply: bad arguments");
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((scale_res_bwd_kernel<T>), dim3(grid_for((int64_t)B * HW * C, 256)), dim3(256), 0, ST, (const T*)dout, sgate, dy_mean, (T*)dx2, (T*)dres, B, HW, C, inv));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_ca_pool_fwd(const void* x, int dtype, int B, int H, int W, int C, float* xh, float* xw, dm_stream_t s) {
+    DM_CHECK_ARG(x && xh && xw && B > 0 && H > 0 && W > 0 && C > 0, "dm_ca_pool_fwd: bad arguments");
+    int rc = launch_strip<0>(x, nullptr, xh, dtype, B, H, W, W, 1, H * W, C, 1.f / (float)W, ST);
+    if (rc) return rc;
+    return launch_strip<0>(x, nullptr, xw, dtype, B, W, H, 1, W, H * W, C, 1.f / (float)H, ST);
+}
+
+extern "C" int dm_ca_pool_bwd(const float* dxh, const float* dxw, const void* dout_gate, void* dx, int dtype, int B, int H, int W, int C,
+                              dm_stream_t s) {
+    DM_CHECK_ARG(dxh && dxw && dx && B > 0 && H > 0 && W > 0 && C > 0, "dm_ca_pool_bwd: bad arguments");
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ca_pool_bwd_kernel<T>), dim3(grid_for((int64_t)B * H * W * C, 256)), dim3(256), 0, ST, dxh, dxw, (const T*)dout_gate, (T*)dx, B, H, W, C));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_ca_gate_fwd(const void* x, const float* lh, const float* lw, const float* alpha, const float* beta, void* out, int dtype,
+                              int B, int H, int W, int C, dm_stream_t s) {
+    DM_CHECK_ARG(x && lh && lw && alpha && beta && out && B > 0 && H > 0 && W > 0 && C > 0, "dm_ca_gate_fwd: bad arguments");
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ca_gate_fwd_kernel<T>), dim3(grid_for((int64_t)B * H * W * C, 256)), dim3(256), 0, ST, (const T*)x, lh, lw, alpha, beta, (T*)out, B, H, W, C));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+// dlh / dlw double as scratch for the strip sums (written in place); dalpha_dbeta: [0..1] += grads, [2..3] scratch (zeroed here)
+extern "C" int dm_ca_gate_bwd(const void* x, const void* dout, const float* lh, const float* lw, const float* alpha, const float* beta,
+                              void* dx_gate, float* dlh, float* dlw, float* dalpha_dbeta, int dtype, int B, int H, int W, int C,
+                              dm_stream_t s) {
+    DM_CHECK_ARG(x && dout && lh && lw && alpha && beta && dx_gate && dlh && dlw && dalpha_dbeta && B > 0 && H > 0 && W > 0 && C > 0,
+                 "dm_ca_gate_bwd: bad arguments");
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ca_gate_bwd_dx_kernel<T>), dim3(grid_for((int64_t)B * H * W * C, 256)), dim3(256), 0, ST, (const T*)dout, lh, lw, alpha, beta, (T*)dx_gate, B, H, W, C));
+    DM_LAUNCH_CHECK();
+    hipError_t e = hipMemsetAsync(dalpha_dbeta + 2, 0, 2 * sizeof(float), ST);
+    if (e != hipSuccess) { dm_set_error("dm_ca_gate_bwd: memset failed"); return (int)e; }
+    int rc = launch_strip<1>(dout, x, dlh, dtype, B, H, W, W, 1, H * W, C, 1.f, ST);
+    if (rc) return rc;
+    rc = launch_strip<1>(dout, x, dlw, dtype, B, W, H, 1, W, H * W, C, 1.f, ST);
+    if (rc) return rc;
+    const int64_t nh = (int64_t)B * H * C, nw = (int64_t)B * W * C;
+    hipLaunchKernelGGL(ca_gate_bwd_strip_kernel, dim3(grid_for(nh, 256, 64)), dim3(256), 0, ST, dlh, lh, alpha, beta, 0, dlh, dalpha_dbeta + 2, nh);
+    hipLaunchKernelGGL(ca_gate_bwd_strip_kernel, dim3(grid_for(nw, 256, 64)), dim3(256), 0, ST, dlw, lw, alpha, beta, 1, dlw, dalpha_dbeta + 2, nw);
+    hipLaunchKernelGGL(ca_mix_bwd_kernel, dim3(1), dim3(64), 0, ST, alpha, beta, dalpha_dbeta + 2, dalpha_dbeta);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_sigmix_fwd(const float* x, const float* y, const float* gamma, float* xo, int n, dm_stream_t s) {
+    DM_CHECK_ARG(x && y && gamma && xo && n > 0, "dm_sigmix_fwd: bad arguments");
+    hipLaunchKernelGGL(sigmix_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST, x, y, gamma, xo, n);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+extern "C" int dm_sigmix_bwd(const float* dxo, const float* y, const float* gamma, float* dy, float* dgamma, int n, dm_stream_t s) {
+    DM_CHECK_ARG(dxo && y && gamma && dy && dgamma && n > 0, "dm_sigmix_bwd: bad arguments");
+    hipLaunchKernelGGL(sigmix_bwd_kernel, dim3(grid_for(n, 256, 64)), dim3(256), 0, ST, dxo, y, gamma, dy, dgamma, n);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act, dm_stream_t s) {
+    DM_CHECK_ARG(x && w && y && M > 0 && K > 0 && N > 0, "dm_linear_fwd: bad arguments");
+    hipLaunchKernelGGL(sgemm_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, ST, x, w, b, y, M, N, K, (int64_t)K, (int64_t)1, (int64_t)1, (int64_t)K, N, act, 0);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int M, int K, int N,
+                             dm_stream_t s) {
+    DM_CHECK_ARG(x && w && dy && M > 0 && K > 0 && N > 0, "dm_linear_bwd: bad arguments");
+    if (dx)  // dx[m][k] = sum_n dy[m][n] w[n][k]
+        hipLaunchKernelGGL(sgemm_kernel, dim3(cdiv(K, 64), cdiv(M, 64)), dim3(256), 0, ST, dy, w, (const float*)nullptr, dx, M, K, N, (int64_t)N, (int64_t)1, (int64_t)K, (int64_t)1, K, 0, 0);
+    if (dw)  // dw[n][k] += sum_m dy[m][n] x[m][k]
+        hipLaunchKernelGGL(sgemm_kernel, dim3(cdiv(K, 64), cdiv(N, 64)), dim3(256), 0, ST, dy, x, (const float*)nullptr, dw, N, K, M, (int64_t)1, (int64_t)N, (int64_t)K, (int64_t)1, K, 0, 1);
+    if (db) hipLaunchKernelGGL(colsum_small_kernel, dim3(cdiv(N, 256)), dim3(256), 0, ST, dy, db, M, N);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_act_fwd(const float* x, float* y, int n, int act, dm_stream_t s) {
+    DM_CHECK_ARG(x && y && n > 0, "dm_act_fwd: bad arguments");
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST, x, y, n, act);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+extern "C" int dm_act_bwd(const float* x, const float* dy, float* dx, int n, int act, dm_stream_t s) {
+    DM_CHECK_ARG(x && dy && dx && n > 0, "dm_act_bwd: bad arguments");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST, x, dy, dx, n, act);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_onehot_mask(const int64_t* c, const float* mask, float* out, int B, int ncls, int flip, dm_stream_t s) {
+    DM_CHECK_ARG(c && mask && out && B > 0 && ncls > 0, "dm_onehot_mask: bad arguments");
+    hipLaunchKernelGGL(onehot_mask_kernel, dim3(cdiv(B * ncls, 256)), dim3(256), 0, ST, c, mask, out, B, ncls, flip);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}

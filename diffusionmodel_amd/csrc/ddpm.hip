@@ -1,0 +1,253 @@
+// DDPM wrapper kernels: q-sample, weighted loss (+ gradient), CFG combine + ancestral update with a
+// device-resident step counter (hipGraph replay needs no host-side arguments), Philox N(0,1),
+// and the fused clip + AdamW optimiser step on flat fp32 buffers.  All HBM-bound.
+#include "common.h"
+
+namespace {
+
+// ---- Philox4x32-10 ---------------------------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+__device__ inline U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+__device__ inline void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+    const float u1 = ((float)a + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]
+    const float u2 = (float)b * 2.3283064365386963e-10f;
+    const float r = sqrtf(-2.0f * __logf(u1));
+    float sn, cs;
+    __sincosf(6.283185307179586f * u2, &sn, &cs);
+    z0 = r * cs;
+    z1 = r * sn;
+}
+__device__ inline void normal4(uint64_t seed, uint64_t ctr_hi, uint64_t ctr_lo, float* z) {
+    const U4 r = philox4x32_10(U4{(uint32_t)ctr_lo, (uint32_t)(ctr_lo >> 32), (uint32_t)ctr_hi, (uint32_t)(ctr_hi >> 32)},
+                               (uint32_t)seed, (uint32_t)(seed >> 32));
+    box_muller(r.x, r.y, z[0], z[1]);
+    box_muller(r.z, r.w, z[2], z[3]);
+}
+
+__global__ void randn_kernel(float* out, int64_t n, uint64_t seed, uint64_t offset) {
+    const int64_t n4 = (n + 3) / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float z[4];
+        normal4(seed, offset, (uint64_t)i, z);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i * 4 + k < n) out[i * 4 + k] = z[k];
+    }
+}
+
+// ---- q-sample: NCHW fp32 -> NHWC T (Cp) ------------------------------------------------------
+template <typename T>
+__global__ void qsample_kernel(const float* x, const float* noise, const int64_t* ts, const float* sqrtab, const float* sqrtmab,
+                               T* xt, int B, int C, int HW, int Cp) {
+    const int64_t total = (int64_t)B * HW * Cp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cp);
+        const int64_t pix = i / Cp;
+        const int p = (int)(pix % HW);
+        const int b = (int)(pix / HW);
+        float v = 0.f;
+        if (c < C) {
+            const size_t j = ((size_t)b * C + c) * HW + p;
+            const int64_t t = ts[b];
+            v = sqrtab[t] * x[j] + sqrtmab[t] * noise[j];
+        }
+        Elem<T>::st(xt + i, v);
+    }
+}
+
+// ---- loss -------------------------------------------------------------------------------------
+__global__ void loss_fwd_kernel(const float* pred, const float* noise, const float* mask, const float* cfg, float* loss, int B, int C,
+                                int HW) {
+    __shared__ float red[16];
+    const int64_t total = (int64_t)B * C * HW;
+    const float inv = 1.f / (float)total;
+    float hi_t = 0, mid_t = 0, hi_w = 1, mid_w = 1, lo_w = 1, feat_w = 0;
+    if (mask) { hi_t = cfg[0]; mid_t = cfg[1]; hi_w = cfg[2]; mid_w = cfg[3]; lo_w = cfg[4]; feat_w = cfg[5]; }
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const float d = noise[i] - pred[i];
+        float w = 1.f, h = 0.f;
+        if (mask) {
+            const int p = (int)(i % HW);
+            const int b = (int)(i / ((int64_t)C * HW));
+            const float m = mask[(size_t)b * HW + p];
+            w = m > hi_t ? hi_w : (m > mid_t ? mid_w : lo_w);
+            h = m > hi_t ? 1.f : 0.f;
+        }
+        s1 += d * d * w;
+        s2 += fabsf(pred[i] * h - noise[i] * h);
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) atomicAdd(loss, s1 * inv + s2 * inv * feat_w);
+}
+
+template <typename T>
+__global__ void loss_bwd_kernel(const float* pred, const float* noise, const float* mask, const float* cfg, const float* gscale,
+                                T* dpred, int B, int C, int HW, int Cp) {
+    const bool nchw = Cp == 0;  // Cp == 0: write NCHW (same indexing as pred), T must be float
+    if (nchw) Cp = C;
+    const int64_t total = (int64_t)B * HW * Cp;
+    const float inv = gscale[0] / (float)((int64_t)B * C * HW);
+    float hi_t = 0, mid_t = 0, hi_w = 1, mid_w = 1, lo_w = 1, feat_w = 0;
+    if (mask) { hi_t = cfg[0]; mid_t = cfg[1]; hi_w = cfg[2]; mid_w = cfg[3]; lo_w = cfg[4]; feat_w = cfg[5]; }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cp);
+        const int64_t pix = i / Cp;
+        const int p = (int)(pix % HW);
+        const int b = (int)(pix / HW);
+        float g = 0.f;
+        if (c < C) {
+            const size_t j = ((size_t)b * C + c) * HW + p;
+            float w = 1.f, h = 0.f;
+            if (mask) {
+                const float m = mask[(size_t)b * HW + p];
+                w = m > hi_t ? hi_w : (m > mid_t ? mid_w : lo_w);
+                h = m > hi_t ? 1.f : 0.f;
+            }
+            const float d = pred[j] - noise[j];
+            const float e = pred[j] * h - noise[j] * h;
+            const float sg = e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f);
+            g = inv * (2.f * w * d + feat_w * h * sg);
+        }
+        if (nchw) { if (c < C) Elem<T>::st(dpred + ((size_t)b * C + c) * HW + p, g); }
+        else Elem<T>::st(dpred + i, g);
+    }
+}
+
+// ---- CFG combine + ancestral update ------------------------------------------------------------
+__global__ void cfg_update_kernel(float* x, const float* eps2n, const float* z, float gw, const float* a_t, const float* b_t,
+                                  const float* s_t, const int32_t* step, uint64_t seed, int64_t n) {
+    const int i_t = step[0];
+    const float a = a_t[i_t], bb = b_t[i_t], sg = i_t > 1 ? s_t[i_t] : 0.f;
+    const int64_t n4 = (n + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+        float zz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (i_t > 1 && !z) normal4(seed, (uint64_t)i_t, (uint64_t)q, zz);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = q * 4 + k;
+            if (i >= n) break;
+            const float e1 = eps2n[i], e2 = eps2n[n + i];
+            const float e = (1.f + gw) * e1 - gw * e2;
+            const float zk = (i_t > 1 && z) ? z[i] : zz[k];
+            x[i] = a * (x[i] - e * bb) + sg * zk;
+        }
+    }
+}
+__global__ void dec_step_kernel(int32_t* step) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) step[0] -= 1;
+}
+__global__ void fill_t_kernel(float* t, const int32_t* step, int n_T, int B) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B) t[i] = (float)step[0] / (float)n_T;
+}
+
+// ---- optimiser -----------------------------------------------------------------------------------
+__global__ void sumsq_kernel(const float* g, int64_t n, float* out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = ((const f32x4*)g)[i];
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) { const float v = g[n4 * 4 + threadIdx.x]; s += v * v; }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hy) {
+    const float lr = hy[0], b1 = hy[1], b2 = hy[2], eps = hy[3], wd = hy[4], max_norm = hy[5], gscale = hy[6], bc1 = hy[7], bc2 = hy[8];
+    float coef = gscale;
+    if (max_norm > 0.f) {
+        const float total = sqrtf(sumsq[0]) * gscale;
+        const float cc = max_norm / (total + 1e-6f);
+        coef *= cc < 1.f ? cc : 1.f;
+    }
+    const float step_size = lr / bc1, rbc2 = 1.f / sqrtf(bc2), decay = 1.f - lr * wd;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gg = g[i] * coef;
+        const float mm = b1 * m[i] + (1.f - b1) * gg;
+        const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+        m[i] = mm;
+        v[i] = vv;
+        p[i] = p[i] * decay - step_size * mm / (sqrtf(vv) * rbc2 + eps);
+    }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)s)
+
+extern "C" int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, dm_stream_t s) {
+    DM_CHECK_ARG(out && n > 0, "dm_randn: bad arguments");
+    hipLaunchKernelGGL(randn_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, ST, out, n, seed, offset);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_qsample(const float* x, const float* noise, const int64_t* ts, const float* sqrtab, const float* sqrtmab, void* xt,
+                          int dtype, int B, int C, int H, int W, int Cp, dm_stream_t s) {
+    DM_CHECK_ARG(x && noise && ts && sqrtab && sqrtmab && xt && B > 0 && C > 0 && H > 0 && W > 0 && Cp >= C, "dm_qsample: bad arguments");
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((qsample_kernel<T>), dim3(grid_for((int64_t)B * H * W * Cp, 256)), dim3(256), 0, ST, x, noise, ts, sqrtab, sqrtmab, (T*)xt, B, C, H * W, Cp));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_loss_fwd(const float* pred, const float* noise, const float* mask, const float* cfg6, float* loss, int B, int C, int H,
+                           int W, dm_stream_t s) {
+    DM_CHECK_ARG(pred && noise && loss && (!mask || cfg6) && B > 0 && C > 0 && H > 0 && W > 0, "dm_loss_fwd: bad arguments");
+    hipLaunchKernelGGL(loss_fwd_kernel, dim3(grid_for((int64_t)B * C * H * W, 256, 512)), dim3(256), 0, ST, pred, noise, mask, cfg6, loss, B, C, H * W);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_loss_bwd(const float* pred, const float* noise, const float* mask, const float* cfg6, const float* gscale, void* dpred,
+                           int dtype, int B, int C, int H, int W, int Cp, dm_stream_t s) {
+    DM_CHECK_ARG(pred && noise && gscale && dpred && (!mask || cfg6) && B > 0 && C > 0 && H > 0 && W > 0 && (Cp >= C || (Cp == 0 && dtype == DM_F32)), "dm_loss_bwd: bad arguments");
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((loss_bwd_kernel<T>), dim3(grid_for((int64_t)B * H * W * (Cp ? Cp : C), 256)), dim3(256), 0, ST, pred, noise, mask, cfg6, gscale, (T*)dpred, B, C, H * W, Cp));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_cfg_update(float* x, const float* eps2n, const float* z, float guide_w, const float* oneover_sqrta,
+                             const float* mab_over_sqrtmab, const float* sqrt_beta_t, int32_t* step, uint64_t seed, int64_t n_elems,
+                             int dec_step, dm_stream_t s) {
+    DM_CHECK_ARG(x && eps2n && oneover_sqrta && mab_over_sqrtmab && sqrt_beta_t && step && n_elems > 0, "dm_cfg_update: bad arguments");
+    hipLaunchKernelGGL(cfg_update_kernel, dim3(grid_for((n_elems + 3) / 4, 256)), dim3(256), 0, ST, x, eps2n, z, guide_w, oneover_sqrta, mab_over_sqrtmab, sqrt_beta_t, step, seed, n_elems);
+    if (dec_step) hipLaunchKernelGGL(dec_step_kernel, dim3(1), dim3(64), 0, ST, step);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_fill_t(float* t, const int32_t* step, int n_T, int B, dm_stream_t s) {
+    DM_CHECK_ARG(t && step && n_T > 0 && B > 0, "dm_fill_t: bad arguments");
+    hipLaunchKernelGGL(fill_t_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ST, t, step, n_T, B);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_sumsq(const float* g, int64_t n, float* out, dm_stream_t s) {
+    DM_CHECK_ARG(g && out && n > 0 && ((uintptr_t)g & 15) == 0, "dm_sumsq: bad arguments (g must be 16-byte aligned)");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1, 256, 1024)), dim3(256), 0, ST, g, n, out);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hyper9, dm_stream_t s) {
+    DM_CHECK_ARG(p && g && m && v && sumsq && hyper9 && n > 0, "dm_adamw: bad arguments");
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST, p, g, m, v, n, sumsq, hyper9);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}

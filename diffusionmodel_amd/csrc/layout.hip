@@ -1,0 +1,448 @@
+// Weight repacks, layout conversion and resampling glue (all HBM-bound, NHWC).
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__global__ void pack_w_kernel(const float* src, T* dst, int64_t rows /*N*T*/, int C, int Cp) {
+    const int64_t total = rows * Cp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / Cp;
+        const int c = (int)(i - r * Cp);
+        Elem<T>::st(dst + i, c < C ? src[r * C + c] : 0.f);
+    }
+}
+
+struct TapList { int32_t t[64]; };
+
+// dst[c][tt][np] = src[n][taps[tt]][c]; 32x32 tile transpose through LDS, grid (Np/32, C/32, Tt)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_wT_kernel(const float* src, T* dst, int N, int Tn, int C, int Tt, int Np, TapList taps) {
+    __shared__ float tile[32][33];
+    const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tt = blockIdx.z;
+    const int ts = taps.t[tt];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + ty + 8 * j, c = c0 + tx;
+        tile[ty + 8 * j][tx] = (n < N && c < C) ? src[((size_t)n * Tn + ts) * C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + 8 * j, n = n0 + tx;
+        if (c < C && n < Np) Elem<T>::st(dst + ((size_t)c * Tt + tt) * Np + n, tile[tx][ty + 8 * j]);
+    }
+}
+
+__global__ void unpad_dw_kernel(const float* src, float* dst, int64_t rows, int C, int Cp, int accumulate) {
+    const int64_t total = rows * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / C;
+        const int c = (int)(i - r * C);
+        const float v = src[r * Cp + c];
+        dst[i] = accumulate ? dst[i] + v : v;
+    }
+}
+
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* x, TO* y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) Elem<TO>::st(y + i, Elem<TI>::ld(x + i));
+}
+
+// NCHW fp32 (B,C,H,W) -> NHWC T (B*repeat, H, W, Cp)
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* x, T* y, int B, int C, int HW, int Cp, int repeat) {
+    const int64_t total = (int64_t)B * repeat * HW * Cp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cp);
+        const int64_t pix = i / Cp;
+        const int p = (int)(pix % HW);
+        const int b = (int)((pix / HW) % B);
+        Elem<T>::st(y + i, c < C ? x[((size_t)b * C + c) * HW + p] : 0.f);
+    }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* x, float* y, int B, int C, int HW, int Cp) {
+    const int64_t total = (int64_t)B * C * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int p = (int)(i % HW);
+        const int c = (int)((i / HW) % C);
+        const int b = (int)(i / ((int64_t)HW * C));
+        y[i] = Elem<T>::ld(x + ((size_t)b * HW + p) * Cp + c);
+    }
+}
+
+template <typename T, int V>
+__device__ inline void ldv(const T* p, float* f) { if constexpr (V == 1) f[0] = Elem<T>::ld(p); else load_vec<T>(p, f); }
+template <typename T, int V>
+__device__ inline void stv(T* p, const float* f) { if constexpr (V == 1) Elem<T>::st(p, f[0]); else store_vec<T>(p, f); }
+
+// ---- FiLM ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void film_fwd_kernel(const T* x, const float* ce, const float* te, T* y, int B, int HW, int C) {
+    const int64_t total = (int64_t)B * HW * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int b = (int)(i / ((int64_t)HW * C));
+        Elem<T>::st(y + i, ce[b * C + c] * Elem<T>::ld(x + i) + te[b * C + c]);
+    }
+}
+// grid (B, ceil(C/256)): thread owns one channel of one sample, loops over pixels
+template <typename T>
+__global__ void film_bwd_kernel(const T* x, const T* dy, const float* ce, T* dx, float* dce, float* dte, int HW, int C) {
+    const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float cev = ce[b * C + c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = 0; p < HW; ++p) {
+        const size_t i = ((size_t)b * HW + p) * C + c;
+        const float g = Elem<T>::ld(dy + i);
+        s1 += g * Elem<T>::ld(x + i);
+        s2 += g;
+        Elem<T>::st(dx + i, g * cev);
+    }
+    dce[b * C + c] = s1;
+    dte[b * C + c] = s2;
+}
+
+// ---- concat + bilinear x2 (align_corners=True) ---------------------------------------------------
+// PyTorch upsample_bilinear2d (align_corners): scale = (in-1)/(out-1); src = scale*dst; i0 = (int)src;
+// i1 = i0 + (i0 < in-1); l1 = src - i0; l0 = 1 - l1.
+__device__ inline void bil_coef(int o, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+    const float src = scale * (float)o;
+    i0 = (int)src;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.f - l1;
+}
+
+template <typename T, int V>
+__global__ void upcat_fwd_kernel(const T* x1, const T* x2, T* y, int B, int H, int W, int C1, int C2) {
+    const int C = C1 + C2, CV = C / V, Ho = 2 * H, Wo = 2 * W;
+    const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const int64_t total = (int64_t)B * Ho * Wo * CV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        int64_t r = i / CV;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        int y0, y1, x0, x1i; float h0, h1, w0, w1;
+        bil_coef(oy, sy, H, y0, y1, h0, h1);
+        bil_coef(ox, sx, W, x0, x1i, w0, w1);
+        const int c = cv * V;
+        const T* src; int Cs, cc;
+        if (c < C1) { src = x1; Cs = C1; cc = c; } else { src = x2; Cs = C2; cc = c - C1; }
+        const T* sb = src + (size_t)b * H * W * Cs + cc;
+        float a[V], bq[V], cq[V], d[V], o[V];
+        ldv<T, V>(sb + ((size_t)y0 * W + x0) * Cs, a);
+        ldv<T, V>(sb + ((size_t)y0 * W + x1i) * Cs, bq);
+        ldv<T, V>(sb + ((size_t)y1 * W + x0) * Cs, cq);
+        ldv<T, V>(sb + ((size_t)y1 * W + x1i) * Cs, d);
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = h0 * (w0 * a[k] + w1 * bq[k]) + h1 * (w0 * cq[k] + w1 * d[k]);
+        stv<T, V>(y + i * V, o);
+    }
+}
+
+struct AxisTaps { int idx[6]; float w[6]; int n; };
+// all output positions o (0..out-1) whose interpolation touches input position i, with weights
+__device__ inline void gather_taps(int i, float scale, int in, int out, AxisTaps& t) {
+    t.n = 0;
+    int lo, hi;
+    if (scale <= 0.f) { lo = 0; hi = out - 1; }
+    else {
+        lo = (int)floorf((float)(i - 1) / scale) - 1;
+        hi = (int)ceilf((float)(i + 1) / scale) + 1;
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > out - 1 ? out - 1 : hi;
+    }
+    for (int o = lo; o <= hi && t.n < 6; ++o) {
+        int i0, i1; float l0, l1;
+        bil_coef(o, scale, in, i0, i1, l0, l1);
+        float w = 0.f;
+        if (i0 == i) w += l0;
+        if (i1 == i) w += l1;
+        if (i0 == i || i1 == i) { t.idx[t.n] = o; t.w[t.n] = w; ++t.n; }
+    }
+}
+
+template <typename T, int V>
+__global__ void upcat_bwd_kernel(const T* dy, T* dx1, T* dx2, int B, int H, int W, int C1, int C2) {
+    const int C = C1 + C2, CV = C / V, Ho = 2 * H, Wo = 2 * W;
+    const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const int64_t total = (int64_t)B * H * W * CV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        int64_t r = i / CV;
+        const int ix = (int)(r % W); r /= W;
+        const int iy = (int)(r % H);
+        const int b = (int)(r / H);
+        AxisTaps ty, tx;
+        gather_taps(iy, sy, H, Ho, ty);
+        gather_taps(ix, sx, W, Wo, tx);
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+        const int c = cv * V;
+        for (int a = 0; a < ty.n; ++a)
+            for (int q = 0; q < tx.n; ++q) {
+                float g[V];
+                ldv<T, V>(dy + (((size_t)b * Ho + ty.idx[a]) * Wo + tx.idx[q]) * C + c, g);
+                const float w = ty.w[a] * tx.w[q];
+#pragma unroll
+                for (int k = 0; k < V; ++k) acc[k] += w * g[k];
+            }
+        if (c < C1) stv<T, V>(dx1 + (((size_t)b * H + iy) * W + ix) * C1 + c, acc);
+        else stv<T, V>(dx2 + (((size_t)b * H + iy) * W + ix) * C2 + (c - C1), acc);
+    }
+}
+
+template <typename T, int V>
+__global__ void cat_kernel(const T* x1, const T* x2, T* y, int64_t M, int C1, int C2, int bwd) {
+    // fwd: y[m] = [x1[m] | x2[m]];  bwd: x1[m], x2[m] <- y[m]  (x pointers are then outputs)
+    const int C = C1 + C2, CV = C / V;
+    const int64_t total = M * CV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % CV) * V;
+        const int64_t m = i / CV;
+        T* p = (c < C1) ? (T*)x1 + m * C1 + c : (T*)x2 + m * C2 + (c - C1);
+        float f[V];
+        if (!bwd) { ldv<T, V>(p, f); stv<T, V>(y + i * V, f); }
+        else { ldv<T, V>(y + i * V, f); stv<T, V>(p, f); }
+    }
+}
+
+// ---- AvgPool k (stride k) + GELU -> fp32 -------------------------------------------------------
+template <typename T>
+__global__ void avgpool_gelu_fwd_kernel(const T* x, float* y, int B, int H, int W, int C, int k) {
+    const int Ho = H / k, Wo = W / k;
+    const int64_t total = (int64_t)B * Ho * Wo * C;
+    const float inv = 1.f / (float)(k * k);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        int64_t r = i / C;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float s = 0.f;
+        for (int dy = 0; dy < k; ++dy)
+            for (int dx = 0; dx < k; ++dx) s += Elem<T>::ld(x + (((size_t)b * H + oy * k + dy) * W + ox * k + dx) * C + c);
+        y[i] = gelu_f(s * inv);
+    }
+}
+template <typename T>
+__global__ void avgpool_gelu_bwd_kernel(const T* x, const float* dy, T* dx, int B, int H, int W, int C, int k) {
+    const int Ho = H / k, Wo = W / k;
+    const int64_t total = (int64_t)B * Ho * Wo * C;
+    const float inv = 1.f / (float)(k * k);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        int64_t r = i / C;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float s = 0.f;
+        for (int dyy = 0; dyy < k; ++dyy)
+            for (int dxx = 0; dxx < k; ++dxx) s += Elem<T>::ld(x + (((size_t)b * H + oy * k + dyy) * W + ox * k + dxx) * C + c);
+        const float g = dy[i] * gelu_grad_f(s * inv) * inv;
+        for (int dyy = 0; dyy < k; ++dyy)
+            for (int dxx = 0; dxx < k; ++dxx) Elem<T>::st(dx + (((size_t)b * H + oy * k + dyy) * W + ox * k + dxx) * C + c, g);
+    }
+}
+
+// ---- MaxPool2d(2) --------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool2_kernel(const T* x, const T* dy, T* out, int B, int H, int W, int C, int bwd) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)B * Ho * Wo * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        int64_t r = i / C;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float best = -INFINITY; int arg = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v = Elem<T>::ld(x + (((size_t)b * H + oy * 2 + (q >> 1)) * W + ox * 2 + (q & 1)) * C + c);
+            if (v > best || v != v) { best = v; arg = q; }
+        }
+        if (!bwd) Elem<T>::st(out + i, best);
+        else {
+            const float g = Elem<T>::ld(dy + i);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                Elem<T>::st(out + (((size_t)b * H + oy * 2 + (q >> 1)) * W + ox * 2 + (q & 1)) * C + c, q == arg ? g : 0.f);
+        }
+    }
+}
+
+template <typename T, int V>
+__global__ void add_kernel(const T* a, const T* b, T* y, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        float fa[V], fb[V];
+        ldv<T, V>(a + i * V, fa);
+        ldv<T, V>(b + i * V, fb);
+#pragma unroll
+        for (int k = 0; k < V; ++k) fa[k] += fb[k];
+        stv<T, V>(y + i * V, fa);
+    }
+}
+
+template <typename T>
+bool al16(int c1, int c2, const void* a, const void* b = nullptr, const void* c = nullptr) {
+    const uintptr_t m = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c;
+    return (c1 % Elem<T>::VE) == 0 && (c2 % Elem<T>::VE) == 0 && (m & 15) == 0;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)s)
+
+extern "C" int dm_pack_w(const float* src, void* dst, int dtype, int N, int T_, int C, int Cp, dm_stream_t s) {
+    DM_CHECK_ARG(src && dst && N > 0 && T_ > 0 && C > 0 && Cp >= C, "dm_pack_w: bad arguments");
+    const int64_t rows = (int64_t)N * T_;
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pack_w_kernel<T>), dim3(grid_for(rows * Cp, 256)), dim3(256), 0, ST, src, (T*)dst, rows, C, Cp));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_pack_wT(const float* src, void* dst, int dtype, int N, int T_, int C, int Tt, const int32_t* taps, int Np, dm_stream_t s) {
+    DM_CHECK_ARG(src && dst && N > 0 && T_ > 0 && C > 0 && Tt > 0 && Tt <= 64 && Np >= N, "dm_pack_wT: bad arguments");
+    TapList tl;
+    for (int i = 0; i < Tt; ++i) {
+        tl.t[i] = taps ? taps[i] : i;
+        DM_CHECK_ARG(tl.t[i] >= 0 && tl.t[i] < T_, "dm_pack_wT: tap %d out of range", tl.t[i]);
+    }
+    dim3 grid(cdiv(Np, 32), cdiv(C, 32), Tt);
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pack_wT_kernel<T>), grid, dim3(256), 0, ST, src, (T*)dst, N, T_, C, Tt, Np, tl));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_unpad_dw(const float* src, float* dst, int N, int T_, int C, int Cp, int accumulate, dm_stream_t s) {
+    DM_CHECK_ARG(src && dst && N > 0 && T_ > 0 && C > 0 && Cp >= C, "dm_unpad_dw: bad arguments");
+    const int64_t rows = (int64_t)N * T_;
+    hipLaunchKernelGGL(unpad_dw_kernel, dim3(grid_for(rows * C, 256)), dim3(256), 0, ST, src, dst, rows, C, Cp, accumulate);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_cast(const void* x, void* y, int from_dtype, int to_dtype, int64_t n, dm_stream_t s) {
+    DM_CHECK_ARG(x && y && n > 0, "dm_cast: bad arguments");
+    const dim3 g(grid_for(n, 256));
+    if (from_dtype == DM_F32 && to_dtype == DM_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), g, dim3(256), 0, ST, (const float*)x, (bf16*)y, n);
+    else if (from_dtype == DM_BF16 && to_dtype == DM_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), g, dim3(256), 0, ST, (const bf16*)x, (float*)y, n);
+    else if (from_dtype == DM_F32 && to_dtype == DM_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, dim3(256), 0, ST, (const float*)x, (float*)y, n);
+    else if (from_dtype == DM_BF16 && to_dtype == DM_BF16) hipLaunchKernelGGL((cast_kernel<bf16, bf16>), g, dim3(256), 0, ST, (const bf16*)x, (bf16*)y, n);
+    else { dm_set_error("dm_cast: bad dtypes %d -> %d", from_dtype, to_dtype); return DM_EINVAL; }
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_nchw_to_nhwc(const float* x, void* y, int dtype, int B, int C, int H, int W, int Cp, int repeat, dm_stream_t s) {
+    DM_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0 && Cp >= C && repeat >= 1, "dm_nchw_to_nhwc: bad arguments");
+    const int64_t total = (int64_t)B * repeat * H * W * Cp;
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, ST, x, (T*)y, B, C, H * W, Cp, repeat));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_nhwc_to_nchw(const void* x, float* y, int dtype, int B, int C, int H, int W, int Cp, dm_stream_t s) {
+    DM_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0 && Cp >= C, "dm_nhwc_to_nchw: bad arguments");
+    const int64_t total = (int64_t)B * C * H * W;
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, ST, (const T*)x, y, B, C, H * W, Cp));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_film_fwd(const void* x, const float* cemb, const float* temb, void* y, int dtype, int B, int HW, int C, dm_stream_t s) {
+    DM_CHECK_ARG(x && cemb && temb && y && B > 0 && HW > 0 && C > 0, "dm_film_fwd: bad arguments");
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((film_fwd_kernel<T>), dim3(grid_for((int64_t)B * HW * C, 256)), dim3(256), 0, ST, (const T*)x, cemb, temb, (T*)y, B, HW, C));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_film_bwd(const void* x, const void* dy, const float* cemb, void* dx, float* dcemb, float* dtemb, int dtype, int B,
+                           int HW, int C, dm_stream_t s) {
+    DM_CHECK_ARG(x && dy && cemb && dx && dcemb && dtemb && B > 0 && HW > 0 && C > 0, "dm_film_bwd: bad arguments");
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((film_bwd_kernel<T>), dim3(B, cdiv(C, 256)), dim3(256), 0, ST, (const T*)x, (const T*)dy, cemb, (T*)dx, dcemb, dtemb, HW, C));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_upcat_fwd(const void* x1, const void* x2, void* y, int dtype, int B, int H, int W, int C1, int C2, dm_stream_t s) {
+    DM_CHECK_ARG(x1 && y && (C2 == 0 || x2) && B > 0 && H > 0 && W > 0 && C1 > 0 && C2 >= 0, "dm_upcat_fwd: bad arguments");
+    const int C = C1 + C2;
+    DM_DISPATCH_DTYPE(dtype, {
+        if (al16<T>(C1, C2, x1, x2, y)) hipLaunchKernelGGL((upcat_fwd_kernel<T, Elem<T>::VE>), dim3(grid_for((int64_t)B * 4 * H * W * C / Elem<T>::VE, 256)), dim3(256), 0, ST, (const T*)x1, (const T*)x2, (T*)y, B, H, W, C1, C2);
+        else hipLaunchKernelGGL((upcat_fwd_kernel<T, 1>), dim3(grid_for((int64_t)B * 4 * H * W * C, 256)), dim3(256), 0, ST, (const T*)x1, (const T*)x2, (T*)y, B, H, W, C1, C2);
+    });
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_upcat_bwd(const void* dy, void* dx1, void* dx2, int dtype, int B, int H, int W, int C1, int C2, dm_stream_t s) {
+    DM_CHECK_ARG(dy && dx1 && (C2 == 0 || dx2) && B > 0 && H > 0 && W > 0 && C1 > 0 && C2 >= 0, "dm_upcat_bwd: bad arguments");
+    const int C = C1 + C2;
+    DM_DISPATCH_DTYPE(dtype, {
+        if (al16<T>(C1, C2, dy, dx1, dx2)) hipLaunchKernelGGL((upcat_bwd_kernel<T, Elem<T>::VE>), dim3(grid_for((int64_t)B * H * W * C / Elem<T>::VE, 256)), dim3(256), 0, ST, (const T*)dy, (T*)dx1, (T*)dx2, B, H, W, C1, C2);
+        else hipLaunchKernelGGL((upcat_bwd_kernel<T, 1>), dim3(grid_for((int64_t)B * H * W * C, 256)), dim3(256), 0, ST, (const T*)dy, (T*)dx1, (T*)dx2, B, H, W, C1, C2);
+    });
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+static int cat_impl(const void* x1, const void* x2, void* y, int dtype, int M, int C1, int C2, int bwd, dm_stream_t s) {
+    DM_CHECK_ARG(x1 && x2 && y && M > 0 && C1 > 0 && C2 > 0, "dm_cat: bad arguments");
+    const int C = C1 + C2;
+    DM_DISPATCH_DTYPE(dtype, {
+        if (al16<T>(C1, C2, x1, x2, y)) hipLaunchKernelGGL((cat_kernel<T, Elem<T>::VE>), dim3(grid_for((int64_t)M * C / Elem<T>::VE, 256)), dim3(256), 0, ST, (const T*)x1, (const T*)x2, (T*)y, (int64_t)M, C1, C2, bwd);
+        else hipLaunchKernelGGL((cat_kernel<T, 1>), dim3(grid_for((int64_t)M * C, 256)), dim3(256), 0, ST, (const T*)x1, (const T*)x2, (T*)y, (int64_t)M, C1, C2, bwd);
+    });
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+extern "C" int dm_cat_fwd(const void* x1, const void* x2, void* y, int dtype, int M, int C1, int C2, dm_stream_t s) { return cat_impl(x1, x2, y, dtype, M, C1, C2, 0, s); }
+extern "C" int dm_cat_bwd(const void* dy, void* dx1, void* dx2, int dtype, int M, int C1, int C2, dm_stream_t s) { return cat_impl(dx1, dx2, (void*)dy, dtype, M, C1, C2, 1, s); }
+
+extern "C" int dm_avgpool_gelu_fwd(const void* x, float* y, int dtype, int B, int H, int W, int C, int k, dm_stream_t s) {
+    DM_CHECK_ARG(x && y && B > 0 && k > 0 && H >= k && W >= k && C > 0, "dm_avgpool_gelu_fwd: bad arguments (H=%d W=%d k=%d)", H, W, k);
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((avgpool_gelu_fwd_kernel<T>), dim3(grid_for((int64_t)B * (H / k) * (W / k) * C, 256)), dim3(256), 0, ST, (const T*)x, y, B, H, W, C, k));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+extern "C" int dm_avgpool_gelu_bwd(const void* x, const float* dy, void* dx, int dtype, int B, int H, int W, int C, int k, dm_stream_t s) {
+    DM_CHECK_ARG(x && dy && dx && B > 0 && k > 0 && H >= k && W >= k && C > 0 && H % k == 0 && W % k == 0, "dm_avgpool_gelu_bwd: bad arguments");
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((avgpool_gelu_bwd_kernel<T>), dim3(grid_for((int64_t)B * (H / k) * (W / k) * C, 256)), dim3(256), 0, ST, (const T*)x, dy, (T*)dx, B, H, W, C, k));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_maxpool2_fwd(const void* x, void* y, int dtype, int B, int H, int W, int C, dm_stream_t s) {
+    DM_CHECK_ARG(x && y && B > 0 && H >= 2 && W >= 2 && C > 0, "dm_maxpool2_fwd: bad arguments");
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((maxpool2_kernel<T>), dim3(grid_for((int64_t)B * (H / 2) * (W / 2) * C, 256)), dim3(256), 0, ST, (const T*)x, (const T*)nullptr, (T*)y, B, H, W, C, 0));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+extern "C" int dm_maxpool2_bwd(const void* x, const void* dy, void* dx, int dtype, int B, int H, int W, int C, dm_stream_t s) {
+    DM_CHECK_ARG(x && dy && dx && B > 0 && H >= 2 && W >= 2 && C > 0 && H % 2 == 0 && W % 2 == 0, "dm_maxpool2_bwd: bad arguments (odd sizes unsupported)");
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((maxpool2_kernel<T>), dim3(grid_for((int64_t)B * (H / 2) * (W / 2) * C, 256)), dim3(256), 0, ST, (const T*)x, (const T*)dy, (T*)dx, B, H, W, C, 1));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_add(const void* a, const void* b, void* y, int dtype, int64_t n, dm_stream_t s) {
+    DM_CHECK_ARG(a && b && y && n > 0, "dm_add: bad arguments");
+    DM_DISPATCH_DTYPE(dtype, {
+        constexpr int V = Elem<T>::VE;
+        const uintptr_t m = (uintptr_t)a | (uintptr_t)b | (uintptr_t)y;
+        if (n % V == 0 && (m & 15) == 0) hipLaunchKernelGGL((add_kernel<T, V>), dim3(grid_for(n / V, 256)), dim3(256), 0, ST, (const T*)a, (const T*)b, (T*)y, n / V);
+        else hipLaunchKernelGGL((add_kernel<T, 1>), dim3(grid_for(n, 256)), dim3(256), 0, ST, (const T*)a, (const T*)b, (T*)y, n);
+    });
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}

@@ -1,0 +1,371 @@
+// BatchNorm (training-mode statistics, fused activation, backward) and GroupNorm on NHWC tensors.
+// All of these are HBM-bound streaming kernels: 16-byte vector accesses along the contiguous channel
+// axis, per-channel reductions done as column sums of the [M][C] matrix (rows = B*H*W) with
+// block-level partials that a second tiny kernel folds (deterministic, no atomics on the hot path).
+#include "common.h"
+
+namespace {
+
+constexpr int CS_ROWS = 512;  // rows per block in column-statistics kernels
+
+// ---------------------------------------------------------------------------------------------
+// Column partial reduction skeleton: block handles rows [r0, r0+CS_ROWS) of an [M][C] matrix.
+// Thread (cv, rl): column vector cv (V elements), row lane rl; LDS folds the row lanes.
+// F: functor (row, col0, float vals_out1[V], float vals_out2[V]) producing two quantities to sum.
+// ---------------------------------------------------------------------------------------------
+template <int V, typename F>
+__device__ inline void col_partial(int M, int C, float* p1, float* p2, F f) {
+    __shared__ float red[2][2048];
+    const int CVt = (C + V - 1) / V;  // column vectors in total
+    const int r0 = blockIdx.x * CS_ROWS;
+    const int r1 = min(r0 + CS_ROWS, M);
+    for (int cbase = 0; cbase < CVt; cbase += 256) {
+        const int ncv = min(256, CVt - cbase);     // column vectors in this chunk
+        const int RL = 256 / ncv;                  // row lanes (>= 1)
+        const int cv = threadIdx.x % ncv, rl = threadIdx.x / ncv;
+        float a1[V], a2[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) a1[i] = a2[i] = 0.f;
+        if (rl < RL) {
+            const int col0 = (cbase + cv) * V;
+            for (int r = r0 + rl; r < r1; r += RL) {
+                float v1[V], v2[V];
+                f(r, col0, v1, v2);
+#pragma unroll
+                for (int i = 0; i < V; ++i) { a1[i] += v1[i]; a2[i] += v2[i]; }
+            }
+        }
+        // fold row lanes: stage to LDS in chunks so that ncv*V*RL floats <= 2048
+        __syncthreads();
+        if (rl < RL) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                red[0][(rl * ncv + cv) * V + i] = a1[i];
+                red[1][(rl * ncv + cv) * V + i] = a2[i];
+            }
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < ncv * V; j += 256) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int l = 0; l < RL; ++l) { s1 += red[0][l * ncv * V + j]; s2 += red[1][l * ncv * V + j]; }
+            const int col = cbase * V + j;
+            if (col < C) {
+                p1[(size_t)blockIdx.x * C + col] = s1;
+                p2[(size_t)blockIdx.x * C + col] = s2;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T, int V>
+__device__ inline void load_cols(const T* p, float* f) {
+    if constexpr (V == 1) f[0] = Elem<T>::ld(p);
+    else load_vec<T>(p, f);
+}
+template <typename T, int V>
+__device__ inline void store_cols(T* p, const float* f) {
+    if constexpr (V == 1) Elem<T>::st(p, f[0]);
+    else store_vec<T>(p, f);
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void col_stats_kernel(const T* z, int M, int C, float* psum, float* psq) {
+    col_partial<V>(M, C, psum, psq, [&](int r, int c0, float* v1, float* v2) {
+        load_cols<T, V>(z + (size_t)r * C + c0, v1);
+#pragma unroll
+        for (int i = 0; i < V; ++i) v2[i] = v1[i] * v1[i];
+    });
+}
+
+// one wave per channel: lanes stride over the partial blocks
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* psum, const float* psq, int nblk, int M, int C,
+                                                          float eps, float mom, float* mean, float* rstd, float* rmean,
+                                                          float* rvar) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = lane; b < nblk; b += 64) { s1 += (double)psum[(size_t)b * C + c]; s2 += (double)psq[(size_t)b * C + c]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (lane == 0) {
+        const double mu = s1 / M;
+        double var = s2 / M - mu * mu;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)mu;
+        rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (rmean) {
+            const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+            rmean[c] = (float)((1.0 - mom) * (double)rmean[c] + mom * mu);
+            rvar[c] = (float)((1.0 - mom) * (double)rvar[c] + mom * unb);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void col_reduce_kernel(const float* part, int nblk, int C, float* out, int accumulate) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = lane; b < nblk; b += 64) s += (double)part[(size_t)b * C + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* z, T* y, int64_t nvec, int CV, const float* mean,
+                                                         const float* rstd, const float* gamma, const float* beta, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(i % CV) * V;
+        float v[V];
+        load_cols<T, V>(z + i * V, v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float g = gamma ? gamma[c0 + k] : 1.f, b = beta ? beta[c0 + k] : 0.f;
+            v[k] = act_apply((v[k] - mean[c0 + k]) * rstd[c0 + k] * g + b, act);
+        }
+        store_cols<T, V>(y + i * V, v);
+    }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* z, const T* dy, int M, int C, const float* mean,
+                                                            const float* rstd, const float* gamma, const float* beta,
+                                                            int act, float* p1, float* p2) {
+    col_partial<V>(M, C, p1, p2, [&](int r, int c0, float* v1, float* v2) {
+        float zz[V], dd[V];
+        load_cols<T, V>(z + (size_t)r * C + c0, zz);
+        load_cols<T, V>(dy + (size_t)r * C + c0, dd);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float xh = (zz[i] - mean[c0 + i]) * rstd[c0 + i];
+            const float u = xh * (gamma ? gamma[c0 + i] : 1.f) + (beta ? beta[c0 + i] : 0.f);
+            const float g = dd[i] * act_grad(u, act);
+            v1[i] = g;
+            v2[i] = g * xh;
+        }
+    });
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* z, const T* dy, T* dz, int64_t nvec, int CV, float invM,
+                                                           const float* mean, const float* rstd, const float* gamma,
+                                                           const float* beta, int act, const float* s1, const float* s2) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(i % CV) * V;
+        float zz[V], dd[V];
+        load_cols<T, V>(z + i * V, zz);
+        load_cols<T, V>(dy + i * V, dd);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const int c = c0 + k;
+            const float gm = gamma ? gamma[c] : 1.f;
+            const float xh = (zz[k] - mean[c]) * rstd[c];
+            const float u = xh * gm + (beta ? beta[c] : 0.f);
+            const float g = dd[k] * act_grad(u, act);
+            zz[k] = gm * rstd[c] * (g - s1[c] * invM - xh * s2[c] * invM);
+        }
+        store_cols<T, V>(dz + i * V, zz);
+    }
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                               const float* cbias, float eps, int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s = gamma[c] / sqrtf(rvar[c] + eps);
+    scale[c] = s;
+    shift[c] = ((cbias ? cbias[c] : 0.f) - rmean[c]) * s + beta[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm: one block per (b, group). Elements: HW pixels x cg channels (contiguous chunk per pixel).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gn_fwd_kernel(const T* x, T* y, int HW, int C, int G, float eps, const float* gamma,
+                                                     const float* beta, int act, float* mean_o, float* rstd_o) {
+    __shared__ float red[16];
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int cg = C / G;
+    const T* xb = x + (size_t)b * HW * C + g * cg;
+    T* yb = y + (size_t)b * HW * C + g * cg;
+    const int n = HW * cg;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int pix = i / cg, c = i - pix * cg;
+        const float v = Elem<T>::ld(xb + (size_t)pix * C + c);
+        s1 += v; s2 += v * v;
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    const float mu = s1 / n;
+    float var = s2 / n - mu * mu;
+    var = var < 0.f ? 0.f : var;
+    const float rs = rsqrtf(var + eps);
+    if (threadIdx.x == 0) { mean_o[blockIdx.x] = mu; rstd_o[blockIdx.x] = rs; }
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int pix = i / cg, c = i - pix * cg;
+        const float v = Elem<T>::ld(xb + (size_t)pix * C + c);
+        const int ch = g * cg + c;
+        Elem<T>::st(yb + (size_t)pix * C + c, act_apply((v - mu) * rs * gamma[ch] + beta[ch], act));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_kernel(const T* x, const T* dy, T* dx, int HW, int C, int G, const float* gamma,
+                                                     const float* beta, int act, const float* mean_i, const float* rstd_i,
+                                                     float* dgamma, float* dbeta) {
+    __shared__ float red[16];
+    extern __shared__ float chacc[];  // [2][cg]
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int cg = C / G;
+    const size_t base = (size_t)b * HW * C + g * cg;
+    const int n = HW * cg;
+    const float mu = mean_i[blockIdx.x], rs = rstd_i[blockIdx.x];
+    for (int i = threadIdx.x; i < 2 * cg; i += 256) chacc[i] = 0.f;
+    __syncthreads();
+    float s1 = 0.f, s2 = 0.f;
+    // thread's channel is i % cg; with 256 % cg == 0 it is fixed per thread, otherwise use LDS atomics per element
+    const bool fixed = (256 % cg) == 0;
+    float cg1 = 0.f, cg2 = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int pix = i / cg, c = i - pix * cg;
+        const int ch = g * cg + c;
+        const float xh = (Elem<T>::ld(x + base + (size_t)pix * C + c) - mu) * rs;
+        const float u = xh * gamma[ch] + beta[ch];
+        const float gg = Elem<T>::ld(dy + base + (size_t)pix * C + c) * act_grad(u, act);
+        s1 += gg * gamma[ch];
+        s2 += gg * gamma[ch] * xh;
+        if (fixed) { cg1 += gg; cg2 += gg * xh; }
+        else { atomicAdd(&chacc[c], gg); atomicAdd(&chacc[cg + c], gg * xh); }
+    }
+    if (fixed && threadIdx.x < n) { const int c = threadIdx.x % cg; atomicAdd(&chacc[c], cg1); atomicAdd(&chacc[cg + c], cg2); }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cg; i += 256) {
+        atomicAdd(dbeta + g * cg + i, chacc[i]);
+        atomicAdd(dgamma + g * cg + i, chacc[cg + i]);
+    }
+    const float m1 = s1 / n, m2 = s2 / n;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int pix = i / cg, c = i - pix * cg;
+        const int ch = g * cg + c;
+        const float xh = (Elem<T>::ld(x + base + (size_t)pix * C + c) - mu) * rs;
+        const float u = xh * gamma[ch] + beta[ch];
+        const float gg = Elem<T>::ld(dy + base + (size_t)pix * C + c) * act_grad(u, act);
+        Elem<T>::st(dx + base + (size_t)pix * C + c, rs * (gg * gamma[ch] - m1 - xh * m2));
+    }
+}
+
+template <typename T>
+bool vec_ok(int C, const void* a, const void* b = nullptr, const void* c = nullptr) {
+    const uintptr_t m = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c;
+    return (C % Elem<T>::VE) == 0 && (m & 15) == 0;
+}
+
+}  // namespace
+
+extern "C" int dm_colstat_blocks(int M) { return cdiv(M, CS_ROWS); }
+
+extern "C" int dm_col_stats(const void* z, int dtype, int M, int C, float* psum, float* psq, dm_stream_t s) {
+    DM_CHECK_ARG(z && psum && psq && M > 0 && C > 0, "dm_col_stats: bad arguments");
+    const int grid = cdiv(M, CS_ROWS);
+    DM_DISPATCH_DTYPE(dtype, {
+        if (vec_ok<T>(C, z)) hipLaunchKernelGGL((col_stats_kernel<T, Elem<T>::VE>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, M, C, psum, psq);
+        else hipLaunchKernelGGL((col_stats_kernel<T, 1>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, M, C, psum, psq);
+    });
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_bn_finalize(const float* psum, const float* psq, int nblk, int M, int C, float eps, float momentum,
+                              float* mean, float* rstd, float* running_mean, float* running_var, dm_stream_t s) {
+    DM_CHECK_ARG(psum && psq && mean && rstd && nblk > 0 && M > 0 && C > 0, "dm_bn_finalize: bad arguments");
+    DM_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "dm_bn_finalize: running_mean/var must come together");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)s, psum, psq, nblk, M, C, eps, momentum,
+                       mean, rstd, running_mean, running_var);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_col_reduce(const float* part, int nblk, int C, float* out, int accumulate, dm_stream_t s) {
+    DM_CHECK_ARG(part && out && nblk > 0 && C > 0, "dm_col_reduce: bad arguments");
+    hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)s, part, nblk, C, out, accumulate);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_bn_act_fwd(const void* z, void* y, int dtype, int M, int C, const float* mean, const float* rstd,
+                             const float* gamma, const float* beta, int act, dm_stream_t s) {
+    DM_CHECK_ARG(z && y && mean && rstd && M > 0 && C > 0, "dm_bn_act_fwd: bad arguments");
+    DM_DISPATCH_DTYPE(dtype, {
+        if (vec_ok<T>(C, z, y)) {
+            constexpr int V = Elem<T>::VE;
+            const int64_t nvec = (int64_t)M * C / V;
+            hipLaunchKernelGGL((bn_act_fwd_kernel<T, V>), dim3(grid_for(nvec, 256)), dim3(256), 0, (hipStream_t)s, (const T*)z, (T*)y, nvec, C / V, mean, rstd, gamma, beta, act);
+        } else {
+            const int64_t nvec = (int64_t)M * C;
+            hipLaunchKernelGGL((bn_act_fwd_kernel<T, 1>), dim3(grid_for(nvec, 256)), dim3(256), 0, (hipStream_t)s, (const T*)z, (T*)y, nvec, C, mean, rstd, gamma, beta, act);
+        }
+    });
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_bn_act_bwd_reduce(const void* z, const void* dy, int dtype, int M, int C, const float* mean, const float* rstd,
+                                    const float* gamma, const float* beta, int act, float* p1, float* p2, dm_stream_t s) {
+    DM_CHECK_ARG(z && dy && mean && rstd && p1 && p2 && M > 0 && C > 0, "dm_bn_act_bwd_reduce: bad arguments");
+    const int grid = cdiv(M, CS_ROWS);
+    DM_DISPATCH_DTYPE(dtype, {
+        if (vec_ok<T>(C, z, dy)) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, Elem<T>::VE>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, p1, p2);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, p1, p2);
+    });
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_bn_act_bwd_apply(const void* z, const void* dy, void* dz, int dtype, int M, int C, const float* mean,
+                                   const float* rstd, const float* gamma, const float* beta, int act, const float* s1,
+                                   const float* s2, dm_stream_t s) {
+    DM_CHECK_ARG(z && dy && dz && mean && rstd && s1 && s2 && M > 0 && C > 0, "dm_bn_act_bwd_apply: bad arguments");
+    const float invM = 1.0f / (float)M;
+    DM_DISPATCH_DTYPE(dtype, {
+        if (vec_ok<T>(C, z, dy, dz)) {
+            constexpr int V = Elem<T>::VE;
+            const int64_t nvec = (int64_t)M * C / V;
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V>), dim3(grid_for(nvec, 256)), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, (T*)dz, nvec, C / V, invM, mean, rstd, gamma, beta, act, s1, s2);
+        } else {
+            const int64_t nvec = (int64_t)M * C;
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), dim3(grid_for(nvec, 256)), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, (T*)dz, nvec, C, invM, mean, rstd, gamma, beta, act, s1, s2);
+        }
+    });
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_bn_fold(const float* gamma, const float* beta, const float* rmean, const float* rvar, const float* conv_bias,
+                          float eps, int C, float* scale, float* shift, dm_stream_t s) {
+    DM_CHECK_ARG(gamma && beta && rmean && rvar && scale && shift && C > 0, "dm_bn_fold: bad arguments");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)s, gamma, beta, rmean, rvar, conv_bias, eps, C, scale, shift);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_gn_act_fwd(const void* x, void* y, int dtype, int B, int HW, int C, int G, float eps, const float* gamma,
+                             const float* beta, int act, float* mean, float* rstd, dm_stream_t s) {
+    DM_CHECK_ARG(x && y && gamma && beta && mean && rstd && B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "dm_gn_act_fwd: bad arguments");
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_fwd_kernel<T>), dim3(B * G), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, HW, C, G, eps, gamma, beta, act, mean, rstd));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_gn_act_bwd(const void* x, const void* dy, void* dx, int dtype, int B, int HW, int C, int G, const float* gamma,
+                             const float* beta, int act, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                             dm_stream_t s) {
+    DM_CHECK_ARG(x && dy && dx && gamma && beta && mean && rstd && dgamma && dbeta && B > 0 && HW > 0 && C % G == 0, "dm_gn_act_bwd: bad arguments");
+    const size_t shm = 2 * (C / G) * sizeof(float);
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_bwd_kernel<T>), dim3(B * G), dim3(256), shm, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, HW, C, G, gamma, beta, act, mean, rstd, dgamma, dbeta));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}

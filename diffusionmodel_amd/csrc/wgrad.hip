@@ -1,0 +1,224 @@
+// Weight gradient of the gather convolution on the matrix cores.
+//
+//   dw[n][t][c] += sum_m dy[orow(m)][n] * in(pix(m,t))[c]
+//
+// GEMM view per tap t: D[i = n][j = c], reduction index k = output pixel m.  In NHWC memory the
+// reduction index is the SLOW index of both operands (rows are pixels), while an MFMA fragment wants
+// consecutive k per lane, so both operands are staged as [pixel][channel] images in LDS and read
+// TRANSPOSED:  bf16 with ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, delivered
+// channel-per-lane), f32 with plain ds_read_b32 (one k per lane, no contiguity needed).
+// k assignment inside a 32-pixel step (bf16): lane group g holds pixels {4g..4g+3} and {16+4g..16+4g+3};
+// A and B use the same assignment, so the MFMA sums every pixel exactly once.  Row stride is padded
+// by 32 B (bf16) / 64 B (f32): the 8 rows a 32-lane half touches per instruction then fall on
+// disjoint banks.
+//
+// Grid: x = 128-wide n tiles, y = taps x 128-wide c tiles, z = split over pixels (fp32 atomics
+// combine the splits — and accumulate into whatever dw already holds, which is how gradient
+// accumulation over micro-batches comes for free).  Blocks with y == 0 also produce dbias.
+#include "common.h"
+
+namespace {
+
+struct WgP {
+    const char* dy; const char* in1; const char* in2; float* dw; float* dbias;
+    int B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0;
+    int Ho, Wo, osy, osx, ooy, oox, N, ldy, ldw, M, csteps_c, steps_per_split, total_steps;
+};
+
+template <typename T> struct WgCfg;
+template <> struct WgCfg<bf16> { static constexpr int KD = 32, STRIDE = 288; };
+template <> struct WgCfg<float> { static constexpr int KD = 16, STRIDE = 576; };
+
+__device__ inline bf16x8 tr_frag(const char* tile, int stride, int col_base, int lane) {
+    // 16x16x32 operand fragment for 16 channels starting at col_base, transposed read.
+    const int g = lane >> 4, il = lane & 15, q = il >> 2, pp = il & 3;
+    const char* a0 = tile + (4 * g + q) * stride + (col_base + 4 * pp) * 2;
+    const char* a1 = a0 + 16 * stride;
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
+    constexpr int VE = Elem<T>::VE;
+    constexpr int KD = WgCfg<T>::KD, STRIDE = WgCfg<T>::STRIDE;
+    constexpr int VPR = 128 / VE;         // vectors per row
+    constexpr int RPP = 256 / VPR;        // rows covered per pass
+    constexpr int TILE = KD * STRIDE;
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, wc = wave >> 1;
+    const int C = p.C1 + p.C2;
+    const int n0 = blockIdx.x * 128;
+    const int t = blockIdx.y / p.csteps_c, c0 = (blockIdx.y - t * p.csteps_c) * 128;
+    const int ky = t / p.KW, kx = t - ky * p.KW;
+    const int dyo = ky * p.ty + p.oy0, dxo = kx * p.tx + p.ox0;
+    const T* dy = (const T*)p.dy;
+    const T* in1 = (const T*)p.in1;
+    const T* in2 = (const T*)p.in2;
+
+    const int svec = tid % VPR, srow = tid / VPR;
+    const int step_lo = blockIdx.z * p.steps_per_split;
+    const int step_hi = min(step_lo + p.steps_per_split, p.total_steps);
+
+    u32x4 ra[2], rb[2];
+    auto gload = [&](int step) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = srow + RPP * i;
+            const int m = step * KD + row;
+            u32x4 va = {0u, 0u, 0u, 0u}, vb = {0u, 0u, 0u, 0u};
+            if (m < p.M) {
+                const int qx = m % p.Wq, tq = m / p.Wq;
+                const int qy = tq % p.Hq, b = tq / p.Hq;
+                const int n = n0 + svec * VE;
+                if (n + VE <= p.ldy) {
+                    const size_t orow = ((size_t)b * p.Ho + qy * p.osy + p.ooy) * p.Wo + qx * p.osx + p.oox;
+                    va = *(const u32x4*)(dy + orow * p.ldy + n);
+                }
+                const int iy = qy * p.sy + dyo, ix = qx * p.sx + dxo;
+                const int c = c0 + svec * VE;
+                if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && c < C) {
+                    const size_t pix = ((size_t)b * p.Hi + iy) * p.Wi + ix;
+                    const T* src = (c < p.C1) ? (in1 + pix * p.C1 + c) : (in2 + pix * p.C2 + (c - p.C1));
+                    vb = *(const u32x4*)src;
+                }
+            }
+            ra[i] = va;
+            rb[i] = vb;
+        }
+    };
+    auto sstore = [&](int buf) {
+        char* sA = smem + buf * 2 * TILE;
+        char* sB = sA + TILE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int off = (srow + RPP * i) * STRIDE + svec * 16;
+            *(u32x4*)(sA + off) = ra[i];
+            *(u32x4*)(sB + off) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bias_acc = 0.f;
+    const bool do_bias = p.dbias != nullptr && blockIdx.y == 0 && tid < 128;
+
+    if (step_lo < step_hi) {
+        gload(step_lo);
+        sstore(0);
+    }
+    __syncthreads();
+    for (int s = step_lo; s < step_hi; ++s) {
+        const int cur = (s - step_lo) & 1;
+        const bool more = s + 1 < step_hi;
+        if (more) gload(s + 1);
+        const char* sA = smem + cur * 2 * TILE;
+        const char* sB = sA + TILE;
+        if constexpr (sizeof(T) == 2) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) fa[it] = tr_frag(sA, STRIDE, wn * 64 + it * 16, lane);
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) fb[jt] = tr_frag(sB, STRIDE, wc * 64 + jt * 16, lane);
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+                    acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[it], fb[jt], acc[it][jt], 0, 0, 0);
+        } else {
+            const int g = lane >> 4, il = lane & 15;
+#pragma unroll
+            for (int ss = 0; ss < KD / 4; ++ss) {
+                float fa[4], fb[4];
+                const int roff = (4 * ss + g) * STRIDE;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) fa[it] = *(const float*)(sA + roff + (wn * 64 + it * 16 + il) * 4);
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) fb[jt] = *(const float*)(sB + roff + (wc * 64 + jt * 16 + il) * 4);
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt)
+                        acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[it], fb[jt], acc[it][jt], 0, 0, 0);
+            }
+        }
+        if (do_bias) {
+#pragma unroll 8
+            for (int r = 0; r < KD; ++r) bias_acc += Elem<T>::ld((const T*)(sA + r * STRIDE) + tid);
+        }
+        if (more) sstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    const int g = lane >> 4, il = lane & 15;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn * 64 + it * 16 + 4 * g + r;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                const int c = c0 + wc * 64 + jt * 16 + il;
+                if (c < C) atomicAdd(p.dw + (size_t)n * p.ldw + (size_t)t * C + c, acc[it][jt][r]);
+            }
+        }
+    if (do_bias && n0 + tid < p.N) atomicAdd(p.dbias + n0 + tid, bias_acc);
+}
+
+template <typename T>
+int launch_wgrad(WgP& p, int splitk_req, hipStream_t st) {
+    constexpr int KD = WgCfg<T>::KD;
+    const int C = p.C1 + p.C2;
+    p.csteps_c = cdiv(C, 128);
+    p.total_steps = cdiv(p.M, KD);
+    const int tiles = cdiv(p.N, 128) * p.T * p.csteps_c;
+    int splitk = splitk_req;
+    if (splitk <= 0) {  // aim at ~1024 workgroups, at least 4 k-steps per split
+        splitk = cdiv(1024, tiles);
+        const int maxsplit = p.total_steps / 4 > 0 ? p.total_steps / 4 : 1;
+        if (splitk > maxsplit) splitk = maxsplit;
+        if (splitk < 1) splitk = 1;
+    }
+    p.steps_per_split = cdiv(p.total_steps, splitk);
+    splitk = cdiv(p.total_steps, p.steps_per_split);
+    dim3 grid(cdiv(p.N, 128), p.T * p.csteps_c, splitk);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T>), grid, dim3(256), 0, st, p);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+}  // namespace
+
+extern "C" int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream) {
+    DM_CHECK_ARG(d != nullptr, "dm_conv_wgrad: null descriptor");
+    DM_CHECK_ARG(d->dtype == DM_F32 || d->dtype == DM_BF16, "dm_conv_wgrad: bad dtype %d", d->dtype);
+    const int ve = d->dtype == DM_BF16 ? 8 : 4;
+    DM_CHECK_ARG(d->dy && d->in1 && d->dw, "dm_conv_wgrad: null tensor pointer");
+    DM_CHECK_ARG(d->C1 > 0 && d->C1 % ve == 0 && d->C2 >= 0 && d->C2 % ve == 0, "dm_conv_wgrad: C1=%d C2=%d must be multiples of %d", d->C1, d->C2, ve);
+    DM_CHECK_ARG(d->C2 == 0 || d->in2, "dm_conv_wgrad: C2 > 0 but in2 is null");
+    DM_CHECK_ARG(d->ldy % ve == 0 && d->ldy >= d->N, "dm_conv_wgrad: ldy=%d invalid for N=%d", d->ldy, d->N);
+    DM_CHECK_ARG(d->ldw >= d->T * (d->C1 + d->C2), "dm_conv_wgrad: ldw=%d < T*C", d->ldw);
+    DM_CHECK_ARG(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Hq > 0 && d->Wq > 0 && d->T > 0 && d->KW > 0 && d->N > 0, "dm_conv_wgrad: non-positive extent");
+    DM_CHECK_ARG((d->Hq - 1) * d->osy + d->ooy < d->Ho && (d->Wq - 1) * d->osx + d->oox < d->Wo && d->ooy >= 0 && d->oox >= 0, "dm_conv_wgrad: output mapping exceeds Ho/Wo");
+    const int64_t M = (int64_t)d->B * d->Hq * d->Wq;
+    DM_CHECK_ARG(M < (1ll << 31), "dm_conv_wgrad: M too large");
+    DM_CHECK_ARG((int64_t)d->T * cdiv(d->C1 + d->C2, 128) < 65536, "dm_conv_wgrad: grid.y too large");
+    WgP p;
+    p.dy = (const char*)d->dy; p.in1 = (const char*)d->in1; p.in2 = (const char*)d->in2; p.dw = d->dw; p.dbias = d->dbias;
+    p.B = d->B; p.Hi = d->Hi; p.Wi = d->Wi; p.C1 = d->C1; p.C2 = d->C2; p.Hq = d->Hq; p.Wq = d->Wq; p.sy = d->sy; p.sx = d->sx;
+    p.T = d->T; p.KW = d->KW; p.ty = d->ty; p.tx = d->tx; p.oy0 = d->oy0; p.ox0 = d->ox0;
+    p.Ho = d->Ho; p.Wo = d->Wo; p.osy = d->osy; p.osx = d->osx; p.ooy = d->ooy; p.oox = d->oox;
+    p.N = d->N; p.ldy = d->ldy; p.ldw = d->ldw; p.M = (int)M;
+    if (d->dtype == DM_BF16) return launch_wgrad<bf16>(p, d->splitk, (hipStream_t)stream);
+    return launch_wgrad<float>(p, d->splitk, (hipStream_t)stream);
+}

@@ -1,0 +1,226 @@
+/*
+ * dm_amd.h — C ABI of libdm_amd.so, the MI355X (gfx950) kernels behind the DDPM / ContextUnet hot
+ * path of Shen-Yuuu/DiffusionModel.
+ *
+ * The reference has no FFI of its own: its hot path is a chain of torch.nn calls inside
+ * new_scripy.py:70-477 (and MNIST_script.py:31-300).  Each entry point below replaces one family of
+ * those calls; the reference call sites are cited per function.  All pointers are DEVICE pointers
+ * unless stated otherwise, all activations are NHWC ("channels last", C contiguous), `dtype` is
+ * DM_F32 or DM_BF16 for activations/packed weights, master weights / statistics / gradients of
+ * parameters are always fp32.  Every function enqueues on `stream` and returns immediately
+ * (no host synchronisation, no allocation: hipGraph-capturable).  Return value: 0 on success,
+ * a negative DM_E* code on invalid arguments, or a positive hipError_t.
+ *
+ * Python binding: diffusionmodel_amd/_lib.py (ctypes).  See INTEGRATION.md.
+ */
+#ifndef DM_AMD_H
+#define DM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dm_stream_t; /* hipStream_t */
+
+enum { DM_F32 = 0, DM_BF16 = 1 };
+enum { DM_ACT_NONE = 0, DM_ACT_GELU = 1, DM_ACT_RELU = 2, DM_ACT_SIGMOID = 3 };
+enum { DM_OK = 0, DM_EINVAL = -1, DM_EUNSUPPORTED = -2 };
+
+int dm_version(void);
+const char* dm_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM gather convolution on MFMA (bf16: v_mfma_f32_16x16x32_bf16, f32: v_mfma_f32_16x16x4_f32).
+ *   out[orow(m)][coff+n] = act( scale[n] * sum_{t<T} sum_{c<C1+C2} in(pix(m,t))[c] * w[n*ldw + t*(C1+C2) + c] + shift[n] )
+ *   m = (b, qy, qx) over B x Hq x Wq;  tap t -> (iy, ix) = (qy*sy + (t/KW)*ty + oy0, qx*sx + (t%KW)*tx + ox0),
+ *   out-of-image taps read zero;  `in` is the channel concatenation of in1 (C1 ch) and in2 (C2 ch, may be 0);
+ *   orow(m) = (b*Ho + qy*osy + ooy)*Wo + qx*osx + oox.
+ * Serves: Conv2d 3x3/s1 (new_scripy.py:184,189,225,243,311,314), 4x4/s2 (:229), 1x1 (:217,222),
+ * ConvTranspose2d k/k (:298; MNIST_script.py:88,141), their input-gradients (with transposed packed
+ * weights) and eval-mode BatchNorm+GELU folded into scale/shift/act (:185-186 etc. under .eval()).
+ * Optional per-channel partial statistics of the pre-activation value (for train-mode BatchNorm):
+ *   psum[mb*N + n], psq[mb*N + n] for each 128-row block mb.
+ * Requirements: C1 % VE == 0, C2 % VE == 0 (VE = 8 for bf16, 4 for f32), ldw % VE == 0.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct DmConv {
+    const void* in1; const void* in2; const void* w;
+    const float* scale; const float* shift;      /* per output channel, may be NULL (1 / 0) */
+    void* out;                                    /* NHWC `dtype`, or NCHW fp32 when out_nchw_f32 */
+    float* psum; float* psq;                      /* NULL or [ceil(M/128)][N] */
+    int32_t dtype, act, out_nchw_f32;
+    int32_t B, Hi, Wi, C1, C2;
+    int32_t Hq, Wq, sy, sx;
+    int32_t T, KW, ty, tx, oy0, ox0;
+    int32_t Ho, Wo, osy, osx, ooy, oox;
+    int32_t N, ldw, ldc, coff;
+} DmConv;
+int dm_conv(const DmConv* d, dm_stream_t stream);
+
+/* Weight gradient of the same gather convolution (fp32 atomics into dw, which the caller zeroes or
+ * accumulates into):  dw[n*ldw + t*C + c] += sum_m dy[orow(m)][n] * in(pix(m,t))[c],
+ * optionally dbias[n] += sum_m dy[orow(m)][n].   dy has row stride ldy (>= N, % VE == 0). */
+typedef struct DmWgrad {
+    const void* dy; const void* in1; const void* in2;
+    float* dw; float* dbias;
+    int32_t dtype;
+    int32_t B, Hi, Wi, C1, C2;
+    int32_t Hq, Wq, sy, sx;
+    int32_t T, KW, ty, tx, oy0, ox0;
+    int32_t Ho, Wo, osy, osx, ooy, oox;
+    int32_t N, ldy, ldw, splitk;
+} DmWgrad;
+int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream);
+
+/* Weight repacks. src is the fp32 master in physical layout [N][T][C] (= torch channels_last of OIHW).
+ *  dm_pack_w:   dst[n][t][cp]      = c < C ? src[n][t][c] : 0          (cast + channel pad), dst dtype
+ *  dm_pack_wT:  dst[c][tt][np]     = n < N ? src[n][taps[tt]][c] : 0   (transpose for input-gradient),
+ *               taps = NULL means identity over T.  `taps` is a HOST pointer (<= 64 entries).
+ *  dm_unpad_dw: dst[n][t][c] (+)= src[n][t][cp] for c < C   (fp32, accumulate != 0 adds) */
+int dm_pack_w(const float* src, void* dst, int dtype, int N, int T, int C, int Cp, dm_stream_t s);
+int dm_pack_wT(const float* src, void* dst, int dtype, int N, int T, int C, int Tt, const int32_t* taps, int Np, dm_stream_t s);
+int dm_unpad_dw(const float* src, float* dst, int N, int T, int C, int Cp, int accumulate, dm_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm2d in training mode (new_scripy.py:79-80,185-186,190-191,218-219,226-227) on an [M][C] matrix
+ * (NHWC flattened), fused with the following activation.
+ * ---------------------------------------------------------------------------------------------- */
+/* partial column sums of z ([M][C], dtype) -> psum/psq [nblk][C], nblk = dm_colstat_blocks(M) */
+int dm_colstat_blocks(int M);
+int dm_col_stats(const void* z, int dtype, int M, int C, float* psum, float* psq, dm_stream_t s);
+/* partials -> mean, rstd (biased var, eps); running stats update with momentum (unbiased var);
+ * running_* may be NULL */
+int dm_bn_finalize(const float* psum, const float* psq, int nblk, int M, int C, float eps, float momentum,
+                   float* mean, float* rstd, float* running_mean, float* running_var, dm_stream_t s);
+/* y = act(gamma*(z-mean)*rstd + beta) */
+int dm_bn_act_fwd(const void* z, void* y, int dtype, int M, int C, const float* mean, const float* rstd,
+                  const float* gamma, const float* beta, int act, dm_stream_t s);
+/* backward pass 1: partial sums of g = dy*act'(.) and g*xhat  -> p1/p2 [nblk][C] */
+int dm_bn_act_bwd_reduce(const void* z, const void* dy, int dtype, int M, int C, const float* mean, const float* rstd,
+                         const float* gamma, const float* beta, int act, float* p1, float* p2, dm_stream_t s);
+/* reduce partials [nblk][C] -> out[C] (out = or += sum) */
+int dm_col_reduce(const float* part, int nblk, int C, float* out, int accumulate, dm_stream_t s);
+/* backward pass 2: dz = gamma*rstd*(g - s1/M - xhat*s2/M); s1 = dbeta, s2 = dgamma (already reduced) */
+int dm_bn_act_bwd_apply(const void* z, const void* dy, void* dz, int dtype, int M, int C, const float* mean,
+                        const float* rstd, const float* gamma, const float* beta, int act,
+                        const float* s1, const float* s2, dm_stream_t s);
+/* eval-mode BN folded to per-channel scale/shift for dm_conv: scale = gamma*rsqrt(var+eps),
+ * shift = (conv_bias - mean)*scale + beta  (conv_bias may be NULL) */
+int dm_bn_fold(const float* gamma, const float* beta, const float* rmean, const float* rvar, const float* conv_bias,
+               float eps, int C, float* scale, float* shift, dm_stream_t s);
+
+/* GroupNorm(G) + activation (new_scripy.py:299-300,312-313,167-168) on NHWC [B][HW][C]. */
+int dm_gn_act_fwd(const void* x, void* y, int dtype, int B, int HW, int C, int G, float eps, const float* gamma,
+                  const float* beta, int act, float* mean, float* rstd, dm_stream_t s);
+/* dgamma/dbeta are accumulated (+=) with atomics: zero them (or pass the running gradient) */
+int dm_gn_act_bwd(const void* x, const void* dy, void* dx, int dtype, int B, int HW, int C, int G, const float* gamma,
+                  const float* beta, int act, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                  dm_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * SE block + residual combine (new_scripy.py:143-158, 196-205): out = (res + x2 * s[b,c]) * inv
+ * ---------------------------------------------------------------------------------------------- */
+int dm_pool_hw(const void* x, int dtype, int B, int HW, int C, float* mean_bc, dm_stream_t s);   /* mean over HW */
+/* the SE excitation MLP itself (fc -> GELU -> fc -> sigmoid, no biases) is dm_linear_* + dm_act_* below */
+int dm_scale_residual_fwd(const void* x2, const void* res, const float* sgate, void* out, int dtype, int B, int HW,
+                          int C, float inv, dm_stream_t s);    /* sgate NULL -> 1 (MNIST block, no SE) */
+int dm_scale_residual_bwd_reduce(const void* dout, const void* x2, int dtype, int B, int HW, int C, float inv,
+                                 float* dsgate, dm_stream_t s);               /* dsgate[b,c] = sum_hw dout*inv*x2 */
+int dm_scale_residual_bwd_apply(const void* dout, const float* sgate, const float* dy_mean, void* dx2, void* dres,
+                                int dtype, int B, int HW, int C, float inv, dm_stream_t s);
+                                                               /* dx2 = dout*inv*s + dy_mean[b,c]/HW ; dres = dout*inv */
+
+/* ------------------------------------------------------------------------------------------------
+ * Coordinate attention (new_scripy.py:97-140): strip pooling and the final gated multiply.
+ * ---------------------------------------------------------------------------------------------- */
+int dm_ca_pool_fwd(const void* x, int dtype, int B, int H, int W, int C, float* xh, float* xw, dm_stream_t s);
+int dm_ca_pool_bwd(const float* dxh, const float* dxw, const void* dout_gate, void* dx, int dtype, int B, int H, int W,
+                   int C, dm_stream_t s);                      /* dx = dout_gate + dxh/W + dxw/H ; dout_gate may be NULL (0) */
+/* out = x * (al*sig(lh[b,y,c]) + be*sig(lw[b,x,c])),  al = sig(alpha)/(sig(alpha)+sig(beta)+1e-8) */
+int dm_ca_gate_fwd(const void* x, const float* lh, const float* lw, const float* alpha, const float* beta, void* out,
+                   int dtype, int B, int H, int W, int C, dm_stream_t s);
+int dm_ca_gate_bwd(const void* x, const void* dout, const float* lh, const float* lw, const float* alpha,
+                   const float* beta, void* dx_gate, float* dlh, float* dlw, float* dalpha_dbeta, int dtype, int B,
+                   int H, int W, int C, dm_stream_t s);
+/* xo = x + sig(gamma)*y on fp32 strips; backward gives dy = sig*dxo and dgamma */
+int dm_sigmix_fwd(const float* x, const float* y, const float* gamma, float* xo, int n, dm_stream_t s);
+int dm_sigmix_bwd(const float* dxo, const float* y, const float* gamma, float* dy, float* dgamma, int n, dm_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small dense layers in fp32 (EmbedFC new_scripy.py:255-268; CoordAttn 1x1 convs on strips :76-91).
+ *   y[M][N] = act(x[M][K] w[N][K]^T + b)
+ * ---------------------------------------------------------------------------------------------- */
+int dm_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act, dm_stream_t s);
+int dm_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int M, int K, int N,
+                  dm_stream_t s);                              /* dw/db accumulate (+=); dx overwritten, may be NULL */
+int dm_act_fwd(const float* x, float* y, int n, int act, dm_stream_t s);
+int dm_act_bwd(const float* x, const float* dy, float* dx, int n, int act, dm_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layout / resampling glue
+ * ---------------------------------------------------------------------------------------------- */
+/* one-hot(c)*mask -> [B][ncls] fp32 (new_scripy.py:334-340); flip != 0 uses -(1-mask) (MNIST_script.py:170) */
+int dm_onehot_mask(const int64_t* c, const float* mask, float* out, int B, int ncls, int flip, dm_stream_t s);
+/* NCHW fp32 -> NHWC dtype with channel pad to Cp (zeros), optional batch repeat (CFG doubling) */
+int dm_nchw_to_nhwc(const float* x, void* y, int dtype, int B, int C, int H, int W, int Cp, int repeat, dm_stream_t s);
+int dm_nhwc_to_nchw(const void* x, float* y, int dtype, int B, int C, int H, int W, int Cp, dm_stream_t s);
+int dm_cast(const void* x, void* y, int from_dtype, int to_dtype, int64_t n, dm_stream_t s);
+/* FiLM: y = cemb[b,c]*x + temb[b,c] (new_scripy.py:348-349) */
+int dm_film_fwd(const void* x, const float* cemb, const float* temb, void* y, int dtype, int B, int HW, int C, dm_stream_t s);
+int dm_film_bwd(const void* x, const void* dy, const float* cemb, void* dx, float* dcemb, float* dtemb, int dtype, int B,
+                int HW, int C, dm_stream_t s);
+/* concat(x1,x2) along C then bilinear x2 upsample, align_corners=True (new_scripy.py:242,251) */
+int dm_upcat_fwd(const void* x1, const void* x2, void* y, int dtype, int B, int H, int W, int C1, int C2, dm_stream_t s);
+int dm_upcat_bwd(const void* dy, void* dx1, void* dx2, int dtype, int B, int H, int W, int C1, int C2, dm_stream_t s);
+/* plain channel concat / split (MNIST UnetUp, MNIST_script.py:95) */
+int dm_cat_fwd(const void* x1, const void* x2, void* y, int dtype, int M, int C1, int C2, dm_stream_t s);
+int dm_cat_bwd(const void* dy, void* dx1, void* dx2, int dtype, int M, int C1, int C2, dm_stream_t s);
+/* AvgPool k (whole-window, stride k) + GELU (new_scripy.py:290) -> fp32 [B][Ho*Wo][C] */
+int dm_avgpool_gelu_fwd(const void* x, float* y, int dtype, int B, int H, int W, int C, int k, dm_stream_t s);
+int dm_avgpool_gelu_bwd(const void* x, const float* dy, void* dx, int dtype, int B, int H, int W, int C, int k, dm_stream_t s);
+/* MaxPool2d(2) (MNIST_script.py:74) */
+int dm_maxpool2_fwd(const void* x, void* y, int dtype, int B, int H, int W, int C, dm_stream_t s);
+int dm_maxpool2_bwd(const void* x, const void* dy, void* dx, int dtype, int B, int H, int W, int C, dm_stream_t s);
+/* y = a + b (skip-connection gradient joins) */
+int dm_add(const void* a, const void* b, void* y, int dtype, int64_t n, dm_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * DDPM wrapper pieces
+ * ---------------------------------------------------------------------------------------------- */
+/* x_t = sqrtab[ts]*x + sqrtmab[ts]*noise, NCHW fp32 in -> NHWC dtype (Cp channels) out (new_scripy.py:408-411) */
+int dm_qsample(const float* x, const float* noise, const int64_t* ts, const float* sqrtab, const float* sqrtmab,
+               void* xt, int dtype, int B, int C, int H, int W, int Cp, dm_stream_t s);
+/* weighted MSE + masked L1 (new_scripy.py:417-437); pred/noise NCHW fp32, mask [B][H][W];
+ * loss (one float, must be zeroed by the caller) ; thresholds/weights: {hi_t, mid_t, hi_w, mid_w, lo_w, feat_w} */
+int dm_loss_fwd(const float* pred, const float* noise, const float* mask, const float* cfg6, float* loss, int B, int C,
+                int H, int W, dm_stream_t s);
+/* d_pred as NHWC dtype with Cp channels (pads zero), or NCHW fp32 when Cp == 0; scaled by *gscale (device scalar) */
+int dm_loss_bwd(const float* pred, const float* noise, const float* mask, const float* cfg6, const float* gscale,
+                void* dpred, int dtype, int B, int C, int H, int W, int Cp, dm_stream_t s);
+/* plain MSE for the MNIST ancestor (MNIST_script.py:252); mask == NULL in dm_loss_* selects it */
+
+/* CFG combine + ancestral update (new_scripy.py:468-475):
+ *   eps = (1+w)*eps[0:n] - w*eps[n:2n];  x = a_i*(x - eps*b_i) + s_i*z ; i = *step (device int32), z = 0 when i == 1.
+ *   tables: oneover_sqrta, mab_over_sqrtmab, sqrt_beta_t.  z == NULL -> Philox(seed, i) in-kernel N(0,1).
+ *   After the update *step is decremented when dec_step != 0 (hipGraph replay needs no host argument). */
+int dm_cfg_update(float* x, const float* eps2n, const float* z, float guide_w, const float* oneover_sqrta,
+                  const float* mab_over_sqrtmab, const float* sqrt_beta_t, int32_t* step, uint64_t seed, int64_t n_elems,
+                  int dec_step, dm_stream_t s);
+/* t[b] = *step / n_T for b < B (feeds the time embedding inside a captured loop) */
+int dm_fill_t(float* t, const int32_t* step, int n_T, int B, dm_stream_t s);
+/* N(0,1) fill by Philox4x32-10 (used for noise when the caller does not inject it) */
+int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, dm_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser: clip_grad_norm_(1.0) + AdamW (new_scripy.py:715-719, 798, 801) on flat fp32 buffers.
+ * ---------------------------------------------------------------------------------------------- */
+int dm_sumsq(const float* g, int64_t n, float* out /* one float, += */, dm_stream_t s);
+/* clip coefficient = min(1, max_norm/(sqrt(*sumsq)*gscale + 1e-6)); gscale folds 1/world etc.
+ * hyper = {lr, beta1, beta2, eps, weight_decay, max_norm, gscale, bias_corr1, bias_corr2} (device) */
+int dm_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hyper9, dm_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DM_AMD_H */
