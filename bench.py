@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Benchmark of the DDPM / ContextUnet hot path on MI355X (BASELINE.json metric: denoiser-steps/sec).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (N=1): BASELINE.json configs[1] — new_scripy.py ContextUnet 64x64, n_feat=128, T=1000, bf16,
+batch 64 per GPU; a "step" is one full training step: DDPM.forward (q-sample + denoiser + weighted loss)
++ backward + clip_grad_norm_(1.0) + AdamW, on synthetic inputs already resident in HBM.
+N>1: one process per GPU (torchrun), batch 64 per rank (weak scaling), RCCL all-reduce of the flat
+gradient; `value` is the whole-job rate N*K/T.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line: `roofline` for the dominant kernel (the bf16 implicit-GEMM convolution:
+algorithmic FLOPs of every launch inside the timed region / HIP-event time of those launches, against the
+2.5 PFLOP/s dense bf16 MFMA peak), `cpu_baseline` (the CPU oracle — a port — timed on the host cores on a
+bounded sample of the same workload) and `sample` (CFG sampling steps/s, n=64 -> denoiser batch 128).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def synthetic_batch(B, S, n_classes, device, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 3, S, S, generator=g).clamp_(-1, 1)
+    c = torch.randint(0, n_classes, (B,), generator=g)
+    am = torch.full((B, S, S), 0.5)
+    am[:, S // 2:, :] = 1.0
+    for i in range(B):
+        y0, x0 = int(torch.randint(0, S // 2, (1,), generator=g)), int(torch.randint(0, S // 2, (1,), generator=g))
+        am[i, y0:y0 + S // 4, x0:x0 + S // 4] = 3.0
+    return x.to(device), c.to(device), am.to(device)
+
+
+def cpu_baseline(args):
+    """The CPU oracle (a port of the reference's algorithm, oracle/unet_ref.py) on the host cores:
+    train step at a reduced batch, scaled linearly to the benchmark batch."""
+    from oracle import unet_ref as O
+    torch.manual_seed(0)
+    cores = torch.get_num_threads()
+    nf, S, Bs = args.n_feat, args.size, args.cpu_batch
+    spec = O.context_unet_spec(3, nf, 4, args.bottleneck_k)
+    net_ref = {}
+    for k, shp in spec.items():        # torch-default-like init, enough for timing
+        if k.endswith("num_batches_tracked"):
+            net_ref["nn_model." + k] = torch.zeros((), dtype=torch.long)
+        elif k.endswith("running_var") or (k.endswith("weight") and len(shp) == 1):
+            net_ref["nn_model." + k] = torch.ones(shp)
+        elif len(shp) >= 2:
+            fan = 1
+            for d in shp[1:]:
+                fan *= d
+            net_ref["nn_model." + k] = (torch.rand(shp) * 2 - 1) / fan ** 0.5
+        else:
+            net_ref["nn_model." + k] = torch.zeros(shp)
+    params = []
+    for k, v in net_ref.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+            params.append(v)
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-5)
+    sched = O.ddpm_schedules(1e-4, 0.02, 1000)
+    x, c, am = synthetic_batch(Bs, S, 4, "cpu")
+    times = []
+    for it in range(1 + args.cpu_iters):
+        t0 = time.perf_counter()
+        ts = torch.randint(1, 1001, (Bs,))
+        noise = torch.randn_like(x)
+        keep = torch.bernoulli(torch.full((Bs,), 0.9))
+        opt.zero_grad()
+        loss = O.ddpm_loss(net_ref, sched, 1000, x, c, am, ts, noise, keep, True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+    t = sum(times) / len(times)
+    scale = args.batch / Bs
+    return {"value": round(1.0 / (t * scale), 5), "unit": "denoiser-steps/s (train, B=%d)" % args.batch, "cores": cores,
+            "kind": "port", "sample": f"oracle train step (fwd+bwd+clip+AdamW) fp32 at B={Bs} x{scale:g} scaled, "
+                                      f"{args.cpu_iters} timed iters, {t:.2f} s/iter"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--n-feat", dest="n_feat", type=int, default=128)
+    ap.add_argument("--bottleneck-k", dest="bottleneck_k", type=int, default=4)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--sample-steps", dest="sample_steps", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
+    ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=8)
+    ap.add_argument("--cpu-iters", dest="cpu_iters", type=int, default=2)
+    ap.add_argument("--buckets", type=int, default=4)
+    args = ap.parse_args()
+
+    import diffusionmodel_amd as D
+    from diffusionmodel_amd import ops, parallel
+    rank, world, local = parallel.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)                 # identical initial weights on every rank
+    net = D.ContextUnet(3, args.n_feat, 4, bottleneck_k=args.bottleneck_k, dtype=dtype)
+    ddpm = D.DDPM(net, (1e-4, 0.02), 1000, dev, drop_prob=0.1)
+    ddpm.train()
+    opt = D.FusedAdamW(ddpm.parameters(), lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, grad_scale=1.0 / world)
+    reducer = parallel.GradReducer(opt.flat_g, n_buckets=args.buckets) if world > 1 else None
+    if world > 1:
+        parallel.broadcast_parameters(opt.flat_p)
+    x, c, am = synthetic_batch(args.batch, args.size, 4, dev, seed=rank)
+
+    def train_step():
+        opt.zero_grad()
+        loss = ddpm(x, c, am)
+        loss.backward()
+        if reducer is not None:
+            reducer.all_reduce()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        train_step()
+    fence()
+    ops.PROFILE = []                       # HIP-event pairs around every MFMA launch, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final_loss = float(loss.item())
+
+    # ---- roofline of the dominant kernel family (implicit-GEMM conv fwd/dgrad + wgrad) from the events
+    fl = {"conv_igemm": [0.0, 0.0, 0], "conv_wgrad": [0.0, 0.0, 0]}
+    for (kind, flops, e0, e1) in prof:
+        fl[kind][0] += flops
+        fl[kind][1] += e0.elapsed_time(e1) * 1e-3
+        fl[kind][2] += 1
+    dom = "conv_igemm"
+    peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+    ach = fl[dom][0] / max(fl[dom][1], 1e-12) / 1e12
+    roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<%s> (fwd + dgrad launches)" % args.dtype,
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "launches": fl[dom][2], "avg_launch_us": round(fl[dom][1] / max(fl[dom][2], 1) * 1e6, 2),
+                "algorithmic_tflop_per_step": round(fl[dom][0] / args.steps / 1e12, 4),
+                "wgrad": {"achieved": round(fl["conv_wgrad"][0] / max(fl["conv_wgrad"][1], 1e-12) / 1e12, 2),
+                          "launches": fl["conv_wgrad"][2],
+                          "algorithmic_tflop_per_step": round(fl["conv_wgrad"][0] / args.steps / 1e12, 4)},
+                "mfma_time_share_of_step": round((fl["conv_igemm"][1] + fl["conv_wgrad"][1]) / elapsed, 4)}
+
+    # ---- CFG sampling rate (rank 0 only, not part of `value`)
+    sample = None
+    if rank == 0 and args.sample_steps > 0:
+        ddpm.eval()
+        n = args.batch
+        ddpm.sample(n, (3, args.size, args.size), dev, guide_w=2.0, steps=2, seed=1)           # warm-up / caches
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ddpm.sample(n, (3, args.size, args.size), dev, guide_w=2.0, steps=args.sample_steps, seed=1, use_graph=True)
+        torch.cuda.synchronize()
+        ts_ = time.perf_counter() - t1
+        sample = {"steps_per_s": round(args.sample_steps / ts_, 3), "n": n, "denoiser_batch": 2 * n, "guide_w": 2.0,
+                  "hipgraph": True, "encoder_dedup": True, "steps_timed": args.sample_steps}
+        ddpm.train()
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        value = world * args.steps / elapsed
+        out = {"metric": "denoiser-steps/sec (train fwd+bwd+clip+AdamW, 64x64, B=64/GPU)", "value": round(value, 4),
+               "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "new_scripy.py ContextUnet %dx%d n_feat=%d T=1000 %s, train step batch=%d per GPU (BASELINE configs[%d])"
+                                      % (args.size, args.size, args.n_feat, args.dtype, args.batch, 1 if world == 1 else 2),
+                          "global_batch": args.batch * world, "bottleneck_k": args.bottleneck_k, "n_classes": 4,
+                          "parallelism": "dp%d" % world, "samples_per_s": round(value * args.batch, 2)},
+               "loss": final_loss, "roofline": roofline, "cpu_baseline": cpu, "sample": sample}
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -251,3 +251,21 @@ extern "C" int dm_adamw(float* p, const float* g, float* m, float* v, int64_t n,
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
+
+// Multi-tensor copy: table[e] = {src_ptr, dst_ptr, count} (fp32 elements), one workgroup per entry chunk.
+namespace {
+__global__ void scatter_copy_kernel(const int64_t* table, int n_entries, int add) {
+    for (int e = blockIdx.x; e < n_entries; e += gridDim.x) {
+        const float* src = (const float*)table[3 * e + 0];
+        float* dst = (float*)table[3 * e + 1];
+        const int64_t n = table[3 * e + 2];
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = add ? dst[i] + src[i] : src[i];
+    }
+}
+}  // namespace
+extern "C" int dm_scatter_copy(const int64_t* table_dev, int n_entries, int add, dm_stream_t s) {
+    DM_CHECK_ARG(table_dev && n_entries > 0, "dm_scatter_copy: bad arguments");
+    hipLaunchKernelGGL(scatter_copy_kernel, dim3(n_entries < 1024 ? n_entries : 1024), dim3(256), 0, ST, table_dev, n_entries, add);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}

@@ -446,3 +446,21 @@ extern "C" int dm_add(const void* a, const void* b, void* y, int dtype, int64_t 
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
+
+// out = (x ? x : 0) + y * [mask[b,pix] > thresh]   (LocalEnhancer, new_scripy.py:172-174)
+namespace {
+template <typename T>
+__global__ void mask_axpy_kernel(const T* x, const T* y, const float* mask, float thresh, T* out, int64_t npix, int C) {
+    const int64_t total = npix * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const float h = mask[i / C] > thresh ? 1.f : 0.f;
+        Elem<T>::st(out + i, (x ? Elem<T>::ld(x + i) : 0.f) + Elem<T>::ld(y + i) * h);
+    }
+}
+}  // namespace
+extern "C" int dm_mask_axpy(const void* x, const void* y, const float* mask, float thresh, void* out, int dtype, int64_t npix, int C, dm_stream_t s) {
+    DM_CHECK_ARG(y && mask && out && npix > 0 && C > 0, "dm_mask_axpy: bad arguments");
+    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((mask_axpy_kernel<T>), dim3(grid_for(npix * C, 256)), dim3(256), 0, ST, (const T*)x, (const T*)y, mask, thresh, (T*)out, npix, C));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}

@@ -1,0 +1,355 @@
+"""The reference's Python class surface (new_scripy.py:70-356) on top of the HIP operator layer.
+
+Every class keeps the reference's constructor signature, attribute names and state_dict() key schema
+(torch.nn layers are used as *parameter holders* so that reference checkpoints load unchanged); the
+`forward`s never call those holders — they call diffusionmodel_amd.ops, i.e. the C-ABI kernels.
+
+Public `forward(x)` of each block takes/returns NCHW fp32 like the reference; inside the network the
+blocks talk NHWC in the compute dtype through `_fwd`.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, DmError
+from .config import Cfg
+
+INV_1414 = 1.0 / 1.414   # the reference divides by the literal 1.414 (new_scripy.py:205)
+
+
+# ------------------------------------------------------------------------------------------------
+class _ToNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype, cp):
+        ctx.c = x.shape[1]
+        return ops.nchw_to_nhwc(x.float(), dtype, cp)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.nhwc_to_nchw(g.contiguous(), ctx.c), None, None
+
+
+class _ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c):
+        ctx.meta = (x.dtype, x.shape[3])
+        return ops.nhwc_to_nchw(x, c)
+
+    @staticmethod
+    def backward(ctx, g):
+        dtype, cp = ctx.meta
+        return ops.nchw_to_nhwc(g.contiguous(), dtype, cp), None
+
+
+def _pad8(c):
+    return (c + 7) // 8 * 8
+
+
+class _HipBlock(nn.Module):
+    """Base: compute dtype handling + NCHW public wrapper + lazy num_batches_tracked flush."""
+    compute_dtype = torch.float32
+
+    def set_compute_dtype(self, dtype):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise DmError(f"compute dtype must be float32 or bfloat16, got {dtype}")
+        for m in self.modules():
+            if isinstance(m, _HipBlock):
+                m.compute_dtype = dtype
+        return self
+
+    def _specs(self):
+        return [v for v in vars(self).values() if isinstance(v, ops.ConvSpec)]
+
+    def _flush_nbt(self):
+        for m in self.modules():
+            if isinstance(m, _HipBlock):
+                for sp in m._specs():
+                    if sp.nbt_pending and sp.bn is not None:
+                        sp.bn.num_batches_tracked += sp.nbt_pending
+                        sp.nbt_pending = 0
+
+    def state_dict(self, *a, **k):
+        self._flush_nbt()
+        return super().state_dict(*a, **k)
+
+    def _nchw_call(self, x, *rest):
+        y = self._fwd(_ToNHWC.apply(x, self.compute_dtype, _pad8(x.shape[1])), *rest)
+        return _ToNCHW.apply(y, self._out_channels())
+
+
+def _conv(cin, cout, k, stride=1, pad=0):
+    m = nn.Conv2d(cin, cout, k, stride, pad)
+    m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    return m
+
+
+def _strip_conv(x, conv):
+    """1x1 conv on an fp32 strip (B, L, C) -> (B, L, C')."""
+    return ops.linear(x, conv.weight, conv.bias)
+
+
+# ------------------------------------------------------------------------------------------------
+class CoordAttn(_HipBlock):
+    """new_scripy.py:70-140.  Strip pooling and the gated multiply are HBM-bound kernels over the big
+    tensor; everything in between lives on (B, L, C/16) fp32 strips."""
+
+    def __init__(self, channel, reduction=16):
+        super().__init__()
+        r = channel // reduction
+        self.channel = channel
+        self.conv1_h, self.conv1_w = _conv(channel, r, 1), _conv(channel, r, 1)
+        self.bn1_h, self.bn1_w = nn.BatchNorm2d(r), nn.BatchNorm2d(r)
+        self.h2w_proj, self.w2h_proj = _conv(r, r, 1), _conv(r, r, 1)
+        self.gamma_h, self.gamma_w = nn.Parameter(torch.zeros(1)), nn.Parameter(torch.zeros(1))
+        self.conv_h, self.conv_w = _conv(r, channel, 1), _conv(r, channel, 1)
+        self.alpha, self.beta = nn.Parameter(torch.zeros(1)), nn.Parameter(torch.zeros(1))
+        self._sp_h = ops.ConvSpec(1, 1, 1, 0, ACT_GELU, self.bn1_h)
+        self._sp_w = ops.ConvSpec(1, 1, 1, 0, ACT_GELU, self.bn1_w)
+
+    def _out_channels(self):
+        return self.channel
+
+    def _fwd(self, x):
+        B, H, W, C = x.shape
+        if H != W:
+            raise DmError("CoordAttn on the HIP path needs H == W (the reference's adaptive pools are then the identity)")
+        xh, xw = ops.PoolStrips.apply(x)                                           # :102-103
+        xh = ops.BnActMatrix.apply(_strip_conv(xh, self.conv1_h), self.bn1_h.weight, self.bn1_h.bias, self.bn1_h, self._sp_h, ACT_GELU)
+        xw = ops.BnActMatrix.apply(_strip_conv(xw, self.conv1_w), self.bn1_w.weight, self.bn1_w.bias, self.bn1_w, self._sp_w, ACT_GELU)
+        h2w = _strip_conv(xh, self.h2w_proj)                                       # :113
+        w2h = _strip_conv(xw, self.w2h_proj)                                       # :114
+        xh = ops.SigMix.apply(xh, w2h, self.gamma_h)                               # :125
+        xw = ops.SigMix.apply(xw, h2w, self.gamma_w)                               # :126
+        lh = _strip_conv(xh, self.conv_h)
+        lw = _strip_conv(xw, self.conv_w)
+        return ops.CaGate.apply(x, lh, lw, self.alpha, self.beta)                  # :128-140
+
+    def forward(self, x):
+        return self._nchw_call(x)
+
+
+class SEBlock(_HipBlock):
+    """new_scripy.py:143-158.  Standalone it is x * s; inside ResConvBlock it is fused with the residual."""
+
+    def __init__(self, channels, reduction=16):
+        super().__init__()
+        self.channels = channels
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Sequential(nn.Linear(channels, channels // reduction, bias=False), nn.GELU(),
+                                nn.Linear(channels // reduction, channels, bias=False), nn.Sigmoid())
+
+    def _out_channels(self):
+        return self.channels
+
+    def _fwd(self, x):
+        zero = torch.zeros_like(x)
+        return ops.SeResidual.apply(x, zero, self.fc[0].weight, self.fc[2].weight, 1.0)
+
+    def forward(self, x):
+        return self._nchw_call(x)
+
+
+class LocalEnhancer(_HipBlock):
+    """new_scripy.py:161-174: x + conv(x) * [mask > thresh], mask (B,H,W).  Inside ContextUnet the reference's
+    call contributes exactly zero, so the network skips it; this is the standalone contract."""
+
+    def __init__(self, in_ch, high_thresh=Cfg.HIGH_THRESH):
+        super().__init__()
+        self.high_thresh = high_thresh
+        self.in_ch = in_ch
+        self.conv = nn.Sequential(_conv(in_ch, in_ch, 3, 1, 1), nn.GroupNorm(8, in_ch), nn.GELU(), _conv(in_ch, in_ch, 3, 1, 1))
+        self._sp = ops.ConvSpec(3, 3, 1, 1)
+
+    def _out_channels(self):
+        return self.in_ch
+
+    def _fwd(self, x, mask):
+        y = ops.conv_bn_act(x, None, self.conv[0], None, self._sp)
+        y = ops.GroupNormAct.apply(y, self.conv[1].weight, self.conv[1].bias, 8, ACT_GELU)
+        y = ops.conv_bn_act(y, None, self.conv[3], None, self._sp)
+        return ops.MaskAxpy.apply(x, y, mask.float().contiguous(), float(self.high_thresh))
+
+    def forward(self, x, mask):
+        return self._nchw_call(x, mask)
+
+
+class ResConvBlock(_HipBlock):
+    """new_scripy.py:176-209 (MNIST_script.py:31-65 when with_se=False)."""
+
+    def __init__(self, in_ch, out_ch, is_res=False, with_se=True):
+        super().__init__()
+        self.same_ch = in_ch == out_ch
+        self.is_res = is_res
+        self.out_ch = out_ch
+        self.conv1 = nn.Sequential(_conv(in_ch, out_ch, 3, 1, 1), nn.BatchNorm2d(out_ch), nn.GELU())
+        self.conv2 = nn.Sequential(_conv(out_ch, out_ch, 3, 1, 1), nn.BatchNorm2d(out_ch), nn.GELU())
+        if with_se:
+            self.se = SEBlock(out_ch) if is_res else None
+        self._with_se = with_se and is_res
+        self._sp1 = ops.ConvSpec(3, 3, 1, 1, ACT_GELU, self.conv1[1])
+        self._sp2 = ops.ConvSpec(3, 3, 1, 1, ACT_GELU, self.conv2[1])
+
+    def _out_channels(self):
+        return self.out_ch
+
+    def _fwd(self, x):
+        x1 = ops.conv_bn_act(x, None, self.conv1[0], self.conv1[1], self._sp1)
+        x2 = ops.conv_bn_act(x1, None, self.conv2[0], self.conv2[1], self._sp2)
+        if not self.is_res:
+            return x2
+        res = x if self.same_ch else x1
+        if self._with_se:
+            return ops.SeResidual.apply(x2, res, self.se.fc[0].weight, self.se.fc[2].weight, INV_1414)
+        return ops.SeResidual.apply(x2, res, None, None, INV_1414)
+
+    def forward(self, x):
+        return self._nchw_call(x)
+
+
+ResidualConvBlock = ResConvBlock   # MNIST_script.py / scripy_old.py spelling
+
+
+class UnetDown(_HipBlock):
+    """new_scripy.py:211-235."""
+
+    def __init__(self, in_ch, out_ch, compress_ratio=4):
+        super().__init__()
+        cc = in_ch // compress_ratio
+        if cc % 8 or out_ch % 8:
+            raise DmError(f"UnetDown({in_ch},{out_ch}): compressed channels {cc} must be a multiple of 8 on the HIP path "
+                          "(choose n_feat % 32 == 0)")
+        self.out_ch = out_ch
+        self.channel_compress = nn.Sequential(_conv(in_ch, cc, 1), nn.BatchNorm2d(cc), nn.GELU())
+        self.ch_adjust = _conv(cc, out_ch, 1)
+        self.down = nn.Sequential(_conv(out_ch, out_ch, 3, 1, 1), nn.BatchNorm2d(out_ch), nn.GELU(),
+                                  ResConvBlock(out_ch, out_ch, is_res=True), _conv(out_ch, out_ch, 4, 2, 1))
+        self._sp_cc = ops.ConvSpec(1, 1, 1, 0, ACT_GELU, self.channel_compress[1])
+        self._sp_adj = ops.ConvSpec(1, 1, 1, 0)
+        self._sp_d0 = ops.ConvSpec(3, 3, 1, 1, ACT_GELU, self.down[1])
+        self._sp_d4 = ops.ConvSpec(4, 4, 2, 1)
+
+    def _out_channels(self):
+        return self.out_ch
+
+    def _fwd(self, x):
+        x = ops.conv_bn_act(x, None, self.channel_compress[0], self.channel_compress[1], self._sp_cc)
+        x = ops.conv_bn_act(x, None, self.ch_adjust, None, self._sp_adj)
+        x = ops.conv_bn_act(x, None, self.down[0], self.down[1], self._sp_d0)
+        x = self.down[3]._fwd(x)
+        return ops.conv_bn_act(x, None, self.down[4], None, self._sp_d4)
+
+    def forward(self, x):
+        return self._nchw_call(x)
+
+
+class UnetUp(_HipBlock):
+    """new_scripy.py:237-253: cat -> bilinear x2 (align_corners) -> conv3x3 -> 2 plain ResConvBlocks."""
+
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.out_ch = out_ch
+        self.model = nn.Sequential(nn.Sequential(nn.Identity(), _conv(in_ch, out_ch, 3, 1, 1)),
+                                   ResConvBlock(out_ch, out_ch), ResConvBlock(out_ch, out_ch))
+        self._sp = ops.ConvSpec(3, 3, 1, 1)
+
+    def _out_channels(self):
+        return self.out_ch
+
+    def _fwd(self, x, skip):
+        u = ops.UpCat.apply(x, skip)
+        u = ops.conv_bn_act(u, None, self.model[0][1], None, self._sp)
+        return self.model[2]._fwd(self.model[1]._fwd(u))
+
+    def forward(self, x, skip):
+        xs = _ToNHWC.apply(x, self.compute_dtype, x.shape[1])
+        ss = _ToNHWC.apply(skip, self.compute_dtype, skip.shape[1])
+        return _ToNCHW.apply(self._fwd(xs, ss), self.out_ch)
+
+
+class EmbedFC(_HipBlock):
+    """new_scripy.py:255-268 (fp32 in every mode)."""
+
+    def __init__(self, input_dim, emb_dim):
+        super().__init__()
+        self.input_dim = input_dim
+        self.model = nn.Sequential(nn.Linear(input_dim, emb_dim), nn.GELU(), nn.Linear(emb_dim, emb_dim))
+
+    def forward(self, x):
+        x = x.reshape(-1, self.input_dim).float()
+        h = ops.Linear.apply(x, self.model[0].weight, self.model[0].bias)
+        h = ops.Act.apply(h, ACT_GELU)
+        return ops.Linear.apply(h, self.model[2].weight, self.model[2].bias)
+
+
+# ------------------------------------------------------------------------------------------------
+class ContextUnet(_HipBlock):
+    """new_scripy.py:270-356.  New keyword arguments (reference-preserving defaults): `bottleneck_k`
+    (AvgPool/ConvTranspose kernel, reference hard-codes 8; 64x64 needs 4 — SURVEY §0.4) and `dtype`."""
+
+    def __init__(self, in_ch=3, n_feat=192, n_classes=10, bottleneck_k=None, dtype=None):
+        super().__init__()
+        if n_feat % 32:
+            raise DmError(f"n_feat={n_feat}: the HIP path needs n_feat % 32 == 0 (channel vectors of 8)")
+        k = Cfg.BOTTLENECK_K if bottleneck_k is None else bottleneck_k
+        self.in_ch, self.n_feat, self.n_classes, self.bottleneck_k = in_ch, n_feat, n_classes, k
+        F = n_feat
+        self.init_conv = ResConvBlock(in_ch, F, is_res=True)
+        self.down1, self.down2 = UnetDown(F, F), UnetDown(F, 2 * F)
+        self.down3, self.down4 = UnetDown(2 * F, 4 * F), UnetDown(4 * F, 8 * F)
+        self.ca1, self.ca2, self.ca3, self.ca4 = CoordAttn(F), CoordAttn(2 * F), CoordAttn(4 * F), CoordAttn(8 * F)
+        self.to_vec = nn.Sequential(nn.AvgPool2d(k), nn.GELU())
+        self.time_emb1, self.time_emb2 = EmbedFC(1, 8 * F), EmbedFC(1, 4 * F)
+        self.ctx_emb1, self.ctx_emb2 = EmbedFC(n_classes, 8 * F), EmbedFC(n_classes, 4 * F)
+        self.up0 = nn.Sequential(nn.ConvTranspose2d(8 * F, 8 * F, k, k), nn.GroupNorm(8, 8 * F), nn.ReLU())
+        self.up0[0].weight.data = self.up0[0].weight.data.contiguous(memory_format=torch.channels_last)
+        self.up1, self.up2 = UnetUp(16 * F, 4 * F), UnetUp(8 * F, 2 * F)
+        self.up3, self.up4 = UnetUp(4 * F, F), UnetUp(2 * F, F)
+        self.local_enhance = LocalEnhancer(F)
+        self.out = nn.Sequential(_conv(2 * F, F, 3, 1, 1), nn.GroupNorm(8, F), nn.ReLU(), _conv(F, in_ch, 3, 1, 1))
+        self._sp_out0 = ops.ConvSpec(3, 3, 1, 1)
+        self._sp_out3 = ops.ConvSpec(3, 3, 1, 1, out_nchw=True)
+        self.set_compute_dtype(Cfg.torch_dtype() if dtype is None else dtype)
+
+    def _out_channels(self):
+        return self.in_ch
+
+    # ---- pieces shared by forward() and the CFG sampler (which runs the encoder once) ----------
+    def encode(self, x):
+        """NCHW fp32 image -> (x0, d1..d4, u1): everything that does not depend on the class context."""
+        ops.L.require_device(x)
+        return self._encode(_ToNHWC.apply(x, self.compute_dtype, _pad8(self.in_ch)))
+
+    def _encode(self, x8):
+        """Same, from an NHWC tensor already in the compute dtype (channels padded to 8)."""
+        x0 = self.init_conv._fwd(x8)
+        d1 = self.ca1._fwd(self.down1._fwd(x0))
+        d2 = self.ca2._fwd(self.down2._fwd(d1))
+        d3 = self.ca3._fwd(self.down3._fwd(d2))
+        d4 = self.ca4._fwd(self.down4._fwd(d3))
+        if d4.shape[1] < self.bottleneck_k or d4.shape[2] < self.bottleneck_k:
+            raise DmError(f"input {tuple(x8.shape[1:3])} is too small for bottleneck_k={self.bottleneck_k}: "
+                          "four stride-2 stages then AvgPool(k) (the reference fails the same way; use bottleneck_k=4 for 64x64)")
+        hidden = ops.AvgPoolGelu.apply(d4, self.bottleneck_k)                                           # :332
+        u1 = ops.ConvTransposeKS.apply(hidden, self.up0[0].weight, self.up0[0].bias, self.compute_dtype)
+        u1 = ops.GroupNormAct.apply(u1, self.up0[1].weight, self.up0[1].bias, 8, ACT_RELU)            # :297-301
+        return x0, d1, d2, d3, d4, u1
+
+    def embed(self, c, t, ctx_mask):
+        oh = ops.onehot_mask(c.long(), ctx_mask.float(), self.n_classes)                                # :334-340
+        t = t.reshape(-1, 1).float()
+        return self.ctx_emb1(oh), self.time_emb1(t), self.ctx_emb2(oh), self.time_emb2(t)
+
+    def decode(self, feats, embs):
+        x0, d1, d2, d3, d4, u1 = feats
+        cemb1, temb1, cemb2, temb2 = embs
+        u2 = self.up1._fwd(ops.Film.apply(u1, cemb1, temb1), d4)                                        # :348
+        u3 = self.up2._fwd(ops.Film.apply(u2, cemb2, temb2), d3)                                        # :349
+        u4 = self.up3._fwd(u3, d2)
+        u5 = self.up4._fwd(u4, d1)
+        # local_enhance(up5, ctx_mask) == up5 in the reference whenever it runs
+        y = ops.conv_bn_act(u5, x0, self.out[0], None, self._sp_out0)                                   # cat fused as 2nd source
+        y = ops.GroupNormAct.apply(y, self.out[1].weight, self.out[1].bias, 8, ACT_RELU)
+        return ops.conv_bn_act(y, None, self.out[3], None, self._sp_out3)                               # NCHW fp32
+
+    def forward(self, x, c, t, ctx_mask):
+        return self.decode(self.encode(x), self.embed(c, t, ctx_mask))

@@ -1,0 +1,863 @@
+"""Operator layer: torch.autograd.Function wrappers over the C-ABI kernels (include/dm_amd.h).
+
+Conventions
+-----------
+* activations are NHWC tensors `(B, H, W, C)`, contiguous, dtype float32 ("fp32 mode", exact-fp32 MFMA,
+  the 1e-4 parity mode) or bfloat16 ("bf16 mode", the throughput mode); C % 8 == 0;
+* parameters stay fp32 in the reference's shapes (OIHW ...) but in channels_last memory format, i.e.
+  physically [O][kh][kw][I] — exactly the K-contiguous row layout the implicit-GEMM kernel reads,
+  so fp32 mode uses the master weights in place and bf16 mode needs only an elementwise cast;
+* strips / gates / embeddings / statistics are fp32;
+* every kernel goes to torch's current stream through ctypes; torch itself is used for allocation
+  and autograd bookkeeping only.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, call, dt, ptr
+
+BN_EPS = 1e-5
+_EPOCH = [0]          # bumped by the fused optimiser: invalidates packed-weight caches
+_CACHE = {}
+PROFILE = None        # bench.py sets this to a list to collect (kind, flops, start_event, end_event)
+
+
+def bump_weight_epoch():
+    _EPOCH[0] += 1
+    _CACHE.clear()
+
+
+def _empty(shape, dtype, ref):
+    return torch.empty(shape, dtype=dtype, device=ref.device)
+
+
+def _zeros(shape, dtype, ref):
+    return torch.zeros(shape, dtype=dtype, device=ref.device)
+
+
+def _cl(w):
+    """Physical [O][kh][kw][I] view of a 4-D parameter (rewrites its storage once if needed)."""
+    if w.dim() == 4 and not w.is_contiguous(memory_format=torch.channels_last):
+        with torch.no_grad():
+            w.data = w.data.contiguous(memory_format=torch.channels_last)
+    return w
+
+
+def _cached(key, w, build):
+    k = (key, w.data_ptr(), w._version, _EPOCH[0])
+    hit = _CACHE.get(k)
+    if hit is None:
+        hit = build()
+        _CACHE[k] = hit
+    return hit
+
+
+def packed_fwd(w, dtype, cp):
+    """[N][T][cp] weights in `dtype` for dm_conv. fp32 without padding is the master itself."""
+    _cl(w)
+    n, c = w.shape[0], w.shape[1]
+    t = w.shape[2] * w.shape[3]
+    if dtype == torch.float32 and cp == c:
+        return w
+
+    def build():
+        out = _empty((n, t, cp), dtype, w)
+        call("dm_pack_w", ptr(w), ptr(out), dt(dtype), n, t, c, cp)
+        return out
+    return _cached(("fwd", dtype, cp), w, build)
+
+
+def packed_T(w, dtype, taps, np_):
+    """[C][len(taps)][np_] transposed weights for the input-gradient GEMM."""
+    _cl(w)
+    n, c = w.shape[0], w.shape[1]
+    t = w.shape[2] * w.shape[3]
+    taps = list(range(t)) if taps is None else list(taps)
+
+    def build():
+        out = _empty((c, len(taps), np_), dtype, w)
+        arr = (C.c_int32 * len(taps))(*taps)
+        call("dm_pack_wT", ptr(w), ptr(out), dt(dtype), n, t, c, len(taps), arr, np_)
+        return out
+    return _cached(("T", dtype, tuple(taps), np_), w, build)
+
+
+# ------------------------------------------------------------------------------------------------
+# dm_conv / dm_conv_wgrad descriptors
+# ------------------------------------------------------------------------------------------------
+def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0,
+               Ho, Wo, N, osy=1, osx=1, ooy=0, oox=0, ldc=None, coff=0, scale=None, shift=None, act=ACT_NONE,
+               psum=None, psq=None, out_nchw=False):
+    d = L.DmConv()
+    d.in1, d.in2, d.w = ptr(in1), ptr(in2), w_ptr
+    d.scale, d.shift, d.out, d.psum, d.psq = ptr(scale), ptr(shift), ptr(out), ptr(psum), ptr(psq)
+    d.dtype, d.act, d.out_nchw_f32 = dt(dtype), act, int(out_nchw)
+    d.B, d.Hi, d.Wi, d.C1, d.C2 = B, Hi, Wi, C1, C2
+    d.Hq, d.Wq, d.sy, d.sx = Hq, Wq, sy, sx
+    d.T, d.KW, d.ty, d.tx, d.oy0, d.ox0 = T, KW, ty, tx, oy0, ox0
+    d.Ho, d.Wo, d.osy, d.osx, d.ooy, d.oox = Ho, Wo, osy, osx, ooy, oox
+    d.N, d.ldw, d.ldc, d.coff = N, ldw, (N if ldc is None else ldc), coff
+    if PROFILE is None:
+        call("dm_conv", C.byref(d))
+    else:   # bench.py: HIP events on the launch stream around this launch + its algorithmic FLOPs
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call("dm_conv", C.byref(d))
+        e1.record()
+        PROFILE.append(("conv_igemm", 2.0 * B * Hq * Wq * N * T * (C1 + C2), e0, e1))
+
+
+def _wgrad_call(dy, in1, in2, dw, dbias, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0, Ho, Wo, N, ldy,
+                ldw, osy=1, osx=1, ooy=0, oox=0, splitk=0):
+    d = L.DmWgrad()
+    d.dy, d.in1, d.in2, d.dw, d.dbias = ptr(dy), ptr(in1), ptr(in2), ptr(dw), ptr(dbias)
+    d.dtype = dt(dtype)
+    d.B, d.Hi, d.Wi, d.C1, d.C2 = B, Hi, Wi, C1, C2
+    d.Hq, d.Wq, d.sy, d.sx = Hq, Wq, sy, sx
+    d.T, d.KW, d.ty, d.tx, d.oy0, d.ox0 = T, KW, ty, tx, oy0, ox0
+    d.Ho, d.Wo, d.osy, d.osx, d.ooy, d.oox = Ho, Wo, osy, osx, ooy, oox
+    d.N, d.ldy, d.ldw, d.splitk = N, ldy, ldw, splitk
+    if PROFILE is None:
+        call("dm_conv_wgrad", C.byref(d))
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call("dm_conv_wgrad", C.byref(d))
+        e1.record()
+        PROFILE.append(("conv_wgrad", 2.0 * B * Hq * Wq * N * T * (C1 + C2), e0, e1))
+
+
+class ConvSpec:
+    """Static description of one conv (+ optional BatchNorm + activation) site."""
+
+    def __init__(self, kh, kw, stride, pad, act=ACT_NONE, bn=None, out_nchw=False):
+        self.kh, self.kw, self.stride, self.pad, self.act, self.bn, self.out_nchw = kh, kw, stride, pad, act, bn, out_nchw
+        self.nbt_pending = 0   # BatchNorm num_batches_tracked increments not yet flushed to the buffer
+
+
+def _bn_eval_fold(spec, bias):
+    bn = spec.bn
+    key = ("fold", bias.data_ptr() if bias is not None else 0, bn.weight._version, bn.bias._version,
+           bn.running_mean._version, bn.running_var._version, getattr(bn, "_stat_epoch", 0))
+
+    def build():
+        n = bn.weight.shape[0]
+        sc, sh = _empty((n,), torch.float32, bn.weight), _empty((n,), torch.float32, bn.weight)
+        call("dm_bn_fold", ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var), ptr(bias), BN_EPS, n,
+             ptr(sc), ptr(sh))
+        return sc, sh
+    return _cached(key, bn.weight, build)
+
+
+class ConvBnAct(torch.autograd.Function):
+    """y = act(BN(conv(cat(x, x2)) + b)) as ONE autograd node.
+
+    train + BN : dm_conv (raw z, per-block column statistics in the epilogue) -> dm_bn_finalize ->
+                 dm_bn_act_fwd; saves x, z and the batch statistics.
+    eval  + BN : BN folded into the conv epilogue (scale/shift/act) when no gradient is needed.
+    no BN      : bias (+act) in the epilogue.
+    backward   : BN/act backward (two streaming passes), input gradient as a gather-GEMM of dz with
+                 transposed packed weights (per output-parity class for strided convs), weight gradient
+                 by dm_conv_wgrad (fp32 atomics; accumulates straight into `w.main_grad` when present).
+    """
+
+    @staticmethod
+    def forward(ctx, x, x2, w, b, gamma, beta, spec, need_grad=True):
+        L.require_device(x, w)
+        x = x.contiguous()
+        x2 = x2.contiguous() if x2 is not None else None
+        B, Hi, Wi, C1 = x.shape
+        C2 = x2.shape[3] if x2 is not None else 0
+        N, Cin = w.shape[0], w.shape[1]
+        dtype = x.dtype
+        s, p = spec.stride, spec.pad
+        Ho = (Hi + 2 * p - spec.kh) // s + 1
+        Wo = (Wi + 2 * p - spec.kw) // s + 1
+        T = spec.kh * spec.kw
+        Cp = C1 + C2
+        if not (Cp == Cin or (C2 == 0 and Cp > Cin and Cp - Cin < 8)):
+            raise L.DmError(f"conv: input has {Cp} channels, weight expects {Cin}")
+        if not spec.out_nchw and N % 8:
+            raise L.DmError(f"conv: Cout={N} must be a multiple of 8 on the HIP path (use n_feat % 32 == 0)")
+        wp = packed_fwd(w, dtype, Cp)
+        M = B * Ho * Wo
+        geom = dict(dtype=dtype, B=B, Hi=Hi, Wi=Wi, C1=C1, C2=C2, Hq=Ho, Wq=Wo, sy=s, sx=s, T=T, KW=spec.kw, ty=1, tx=1,
+                    oy0=-p, ox0=-p, Ho=Ho, Wo=Wo, N=N)
+        bn = spec.bn
+        ctx.spec, ctx.geom, ctx.has_bn, ctx.C2, ctx.Cin = spec, geom, bn is not None, C2, Cin
+        ctx.bias_present = b is not None
+        if bn is None:
+            if spec.out_nchw:
+                out = _empty((B, N, Ho, Wo), torch.float32, x)
+            else:
+                out = _empty((B, Ho, Wo, N), dtype, x)
+            if spec.act != ACT_NONE and need_grad:
+                raise L.DmError("conv without BN: fused activation has no backward; use a separate activation")
+            _conv_call(x, x2, ptr(wp), T * Cp, out, shift=b, act=spec.act, out_nchw=spec.out_nchw, **geom)
+            ctx.save_for_backward(x, x2, w)
+            return out
+        train = bn.training
+        if not train and not need_grad:
+            sc, sh = _bn_eval_fold(spec, b)
+            out = _empty((B, Ho, Wo, N), dtype, x)
+            _conv_call(x, x2, ptr(wp), T * Cp, out, scale=sc, shift=sh, act=spec.act, **geom)
+            return out
+        z = _empty((B, Ho, Wo, N), dtype, x)
+        mean, rstd = _empty((N,), torch.float32, x), _empty((N,), torch.float32, x)
+        if train:
+            nblk = (M + 127) // 128
+            psum, psq = _empty((nblk, N), torch.float32, x), _empty((nblk, N), torch.float32, x)
+            _conv_call(x, x2, ptr(wp), T * Cp, z, shift=b, psum=psum, psq=psq, **geom)
+            call("dm_bn_finalize", ptr(psum), ptr(psq), nblk, M, N, BN_EPS, bn.momentum, ptr(mean), ptr(rstd),
+                 ptr(bn.running_mean), ptr(bn.running_var))
+            spec.nbt_pending += 1
+            bn._stat_epoch = getattr(bn, "_stat_epoch", 0) + 1
+        else:  # eval mode with autograd: normalise with the running statistics, unfused
+            _conv_call(x, x2, ptr(wp), T * Cp, z, shift=b, **geom)
+            call("dm_bn_fold", ptr(torch.ones_like(mean)), ptr(torch.zeros_like(mean)), ptr(torch.zeros_like(mean)),
+                 ptr(bn.running_var), None, BN_EPS, N, ptr(rstd), ptr(mean))   # rstd = rsqrt(var+eps)
+            mean = bn.running_mean.clone()
+        out = _empty((B, Ho, Wo, N), dtype, x)
+        call("dm_bn_act_fwd", ptr(z), ptr(out), dt(dtype), M, N, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), spec.act)
+        ctx.train = train
+        ctx.save_for_backward(x, x2, w, z, mean, rstd, gamma, beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        spec, geom = ctx.spec, ctx.geom
+        dtype = geom["dtype"]
+        B, Hi, Wi, C1, C2 = geom["B"], geom["Hi"], geom["Wi"], geom["C1"], ctx.C2
+        Ho, Wo, N, T = geom["Ho"], geom["Wo"], geom["N"], geom["T"]
+        M = B * Ho * Wo
+        dgamma = dbeta = None
+        if ctx.has_bn:
+            x, x2, w, z, mean, rstd, gamma, beta = ctx.saved_tensors
+            g = g.contiguous()
+            nblk = L.colstat_blocks(M)
+            p1, p2 = _empty((nblk, N), torch.float32, g), _empty((nblk, N), torch.float32, g)
+            call("dm_bn_act_bwd_reduce", ptr(z), ptr(g), dt(dtype), M, N, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), spec.act,
+                 ptr(p1), ptr(p2))
+            dbeta, dgamma = _empty((N,), torch.float32, g), _empty((N,), torch.float32, g)
+            call("dm_col_reduce", ptr(p1), nblk, N, ptr(dbeta), 0)
+            call("dm_col_reduce", ptr(p2), nblk, N, ptr(dgamma), 0)
+            dz = _empty(z.shape, dtype, g)
+            if ctx.train:
+                s1, s2 = dbeta, dgamma
+            else:
+                s1 = s2 = _zeros((N,), torch.float32, g)
+            call("dm_bn_act_bwd_apply", ptr(z), ptr(g), ptr(dz), dt(dtype), M, N, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+                 spec.act, ptr(s1), ptr(s2))
+            ldy = N
+        else:
+            x, x2, w = ctx.saved_tensors
+            if spec.out_nchw:
+                ldy = (N + 7) // 8 * 8
+                dz = _empty((B, Ho, Wo, ldy), dtype, g)
+                call("dm_nchw_to_nhwc", ptr(g.contiguous().float()), ptr(dz), dt(dtype), B, N, Ho, Wo, ldy, 1)
+            else:
+                dz, ldy = g.contiguous(), N
+        needs = ctx.needs_input_grad
+        Cin, Cp = ctx.Cin, C1 + C2
+        s, p, kh, kw = spec.stride, spec.pad, spec.kh, spec.kw
+        dx = dx2 = dw = db = None
+        # ---- input gradient: gather-GEMM of dz with transposed weights, one launch per output parity class
+        if needs[0] or (x2 is not None and needs[1]):
+            targets = [(0, C1, needs[0])] + ([(C1, C2, needs[1])] if x2 is not None else [])
+            outs = []
+            for (c_lo, c_n, need) in targets:
+                if not need:
+                    outs.append(None)
+                    continue
+                dxi = _empty((B, Hi, Wi, c_n), dtype, g)
+                if (kh % s) or (kw % s):
+                    raise L.DmError("conv backward: kernel size must be a multiple of the stride")
+                if c_lo + c_n > Cin:       # padded stem input: its gradient is never needed
+                    raise L.DmError("conv backward: gradient w.r.t. a channel-padded input is not supported")
+                if Hi % s or Wi % s:
+                    raise L.DmError("conv backward: strided conv needs input size divisible by the stride")
+                for py in range(s):
+                    for px in range(s):
+                        ky0, kx0 = (py + p) % s, (px + p) % s
+                        taps = [(ky0 + s * a) * kw + (kx0 + s * bq) for a in range(kh // s) for bq in range(kw // s)]
+                        wt = packed_T(w, dtype, taps, ldy)
+                        # rows c_lo .. c_lo+c_n of the [C][Tt][ldy] pack
+                        row_bytes = len(taps) * ldy * wt.element_size()
+                        _conv_call(dz, None, wt.data_ptr() + c_lo * row_bytes, len(taps) * ldy, dxi, dtype=dtype, B=B, Hi=Ho, Wi=Wo,
+                                   C1=ldy, C2=0, Hq=Hi // s, Wq=Wi // s, sy=1, sx=1, T=len(taps), KW=kw // s, ty=-1, tx=-1,
+                                   oy0=(py + p - ky0) // s, ox0=(px + p - kx0) // s, Ho=Hi, Wo=Wi, osy=s, osx=s, ooy=py, oox=px,
+                                   N=c_n)
+                outs.append(dxi)
+            dx = outs[0]
+            dx2 = outs[1] if x2 is not None else None
+        # ---- weight / bias gradient
+        if needs[2] or (ctx.bias_present and needs[3]):
+            main = getattr(w, "main_grad", None)
+            wg_geom = dict(dtype=dtype, B=B, Hi=Hi, Wi=Wi, C1=C1, C2=C2, Hq=Ho, Wq=Wo, sy=s, sx=s, T=T, KW=kw, ty=1, tx=1,
+                           oy0=-p, ox0=-p, Ho=Ho, Wo=Wo, N=N, ldy=ldy, ldw=T * Cp)
+            if ctx.bias_present:
+                db = _zeros((N,), torch.float32, g)
+            if Cp == Cin:
+                if main is not None:
+                    tgt = main
+                else:
+                    tgt = _zeros((N, kh, kw, Cin), torch.float32, g)
+                _wgrad_call(dz, x, x2, tgt, db, **wg_geom)
+                dw = None if main is not None else tgt.permute(0, 3, 1, 2)
+            else:
+                tmp = _zeros((N, T, Cp), torch.float32, g)
+                _wgrad_call(dz, x, x2, tmp, db, **wg_geom)
+                if main is not None:
+                    call("dm_unpad_dw", ptr(tmp), ptr(main), N, T, Cin, Cp, 1)
+                else:
+                    tgt = _empty((N, kh, kw, Cin), torch.float32, g)
+                    call("dm_unpad_dw", ptr(tmp), ptr(tgt), N, T, Cin, Cp, 0)
+                    dw = tgt.permute(0, 3, 1, 2)
+        return dx, dx2, dw, db, dgamma, dbeta, None, None
+
+
+def conv_bn_act(x, x2, conv, bn, spec):
+    """conv: holder with .weight/.bias (nn.Conv2d); bn: nn.BatchNorm2d holder or None."""
+    gamma = bn.weight if bn is not None else None
+    beta = bn.bias if bn is not None else None
+    need_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (x, x2, conv.weight, conv.bias, gamma, beta))
+    return ConvBnAct.apply(x, x2, conv.weight, conv.bias, gamma, beta, spec, need_grad)
+
+
+# ------------------------------------------------------------------------------------------------
+# ConvTranspose2d with kernel == stride (non-overlapping): a plain GEMM + scatter
+# ------------------------------------------------------------------------------------------------
+class ConvTransposeKS(torch.autograd.Function):
+    """out[b, y*k+ky, x*k+kx, co] = sum_ci in[b,y,x,ci] W[ci,co,ky,kx] + bias[co]   (new_scripy.py:298, MNIST_script.py:88,141)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, dtype):
+        L.require_device(x, w)
+        B, h, wd, Cin = x.shape
+        Cout, k = w.shape[1], w.shape[2]
+        if x.dtype != dtype:
+            xin = _empty(x.shape, dtype, x)
+            call("dm_cast", ptr(x.contiguous()), ptr(xin), dt(x.dtype), dt(dtype), x.numel())
+        else:
+            xin = x.contiguous()
+        _cl(w)                                        # physical [Cin][k][k][Cout]
+        T = k * k
+
+        def build():                                  # forward pack: [(t,co)][ci]
+            o = _empty((T * Cout, Cin), dtype, w)
+            call("dm_pack_wT", ptr(w), ptr(o), dt(dtype), Cin, 1, T * Cout, 1, None, Cin)
+            return o
+        wf = _cached(("ctf", dtype), w, build)
+        out = _empty((B, h * k, wd * k, Cout), dtype, x)
+        bias_rep = b
+        if h == 1 and wd == 1:
+            def build_b():
+                return b.detach().repeat(T).contiguous()
+            bias_rep = _cached(("ctb", T), b, build_b)
+            _conv_call(xin, None, ptr(wf), Cin, out, dtype=dtype, B=B, Hi=1, Wi=1, C1=Cin, C2=0, Hq=1, Wq=1, sy=1, sx=1, T=1, KW=1,
+                       ty=1, tx=1, oy0=0, ox0=0, Ho=1, Wo=1, N=T * Cout, shift=bias_rep)
+        else:
+            for t in range(T):
+                _conv_call(xin, None, wf.data_ptr() + t * Cout * Cin * wf.element_size(), Cin, out, dtype=dtype, B=B, Hi=h, Wi=wd,
+                           C1=Cin, C2=0, Hq=h, Wq=wd, sy=1, sx=1, T=1, KW=1, ty=1, tx=1, oy0=0, ox0=0, Ho=h * k, Wo=wd * k,
+                           osy=k, osx=k, ooy=t // k, oox=t % k, N=Cout, shift=b)
+        ctx.save_for_backward(xin, w)
+        ctx.meta = (B, h, wd, Cin, Cout, k, dtype, x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xin, w = ctx.saved_tensors
+        B, h, wd, Cin, Cout, k, dtype, xdtype = ctx.meta
+        g = g.contiguous()
+        T = k * k
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wd_ = packed_fwd(w, dtype, Cout)          # [Cin][T][Cout]: rows = ci, K = (t, co)
+            dxi = _empty((B, h, wd, Cin), dtype, g)
+            _conv_call(g, None, ptr(wd_), T * Cout, dxi, dtype=dtype, B=B, Hi=h * k, Wi=wd * k, C1=Cout, C2=0, Hq=h, Wq=wd, sy=k, sx=k,
+                       T=T, KW=k, ty=1, tx=1, oy0=0, ox0=0, Ho=h, Wo=wd, N=Cin)
+            if xdtype != dtype:
+                dx = _empty(dxi.shape, xdtype, g)
+                call("dm_cast", ptr(dxi), ptr(dx), dt(dtype), dt(xdtype), dxi.numel())
+            else:
+                dx = dxi
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            main = getattr(w, "main_grad", None)
+            tgt = main if main is not None else _zeros((Cin, k, k, Cout), torch.float32, g)
+            # "dy" role = the ConvT input (N = Cin), "in" role = g gathered with taps (ky,kx), stride k
+            _wgrad_call(xin, g, None, tgt, None, dtype=dtype, B=B, Hi=h * k, Wi=wd * k, C1=Cout, C2=0, Hq=h, Wq=wd, sy=k, sx=k, T=T, KW=k,
+                        ty=1, tx=1, oy0=0, ox0=0, Ho=h, Wo=wd, N=Cin, ldy=Cin, ldw=T * Cout)
+            dw = None if main is not None else tgt.permute(0, 3, 1, 2)
+            # bias gradient: column sums of g over all pixels
+            M = B * h * k * wd * k
+            nblk = L.colstat_blocks(M)
+            p1, p2 = _empty((nblk, Cout), torch.float32, g), _empty((nblk, Cout), torch.float32, g)
+            call("dm_col_stats", ptr(g), dt(dtype), M, Cout, ptr(p1), ptr(p2))
+            db = _empty((Cout,), torch.float32, g)
+            call("dm_col_reduce", ptr(p1), nblk, Cout, ptr(db), 0)
+        return dx, dw, db, None
+
+
+# ------------------------------------------------------------------------------------------------
+# GroupNorm + activation
+# ------------------------------------------------------------------------------------------------
+class GroupNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, act):
+        L.require_device(x)
+        x = x.contiguous()
+        B, H, W, Cc = x.shape
+        y = _empty(x.shape, x.dtype, x)
+        mean, rstd = _empty((B * groups,), torch.float32, x), _empty((B * groups,), torch.float32, x)
+        call("dm_gn_act_fwd", ptr(x), ptr(y), dt(x), B, H * W, Cc, groups, BN_EPS, ptr(gamma), ptr(beta), act, ptr(mean), ptr(rstd))
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.meta = (groups, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        groups, act = ctx.meta
+        B, H, W, Cc = x.shape
+        g = g.contiguous()
+        dx = _empty(x.shape, x.dtype, x)
+        dgamma, dbeta = _zeros((Cc,), torch.float32, x), _zeros((Cc,), torch.float32, x)
+        call("dm_gn_act_bwd", ptr(x), ptr(g), ptr(dx), dt(x), B, H * W, Cc, groups, ptr(gamma), ptr(beta), act, ptr(mean), ptr(rstd),
+             ptr(dgamma), ptr(dbeta))
+        return dx, dgamma, dbeta, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# fp32 dense layers / activations on small matrices
+# ------------------------------------------------------------------------------------------------
+class Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        L.require_device(x, w)
+        x = x.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        y = _empty((M, N), torch.float32, x)
+        call("dm_linear_fwd", ptr(x), ptr(w), ptr(b), ptr(y), M, K, N, ACT_NONE)
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        dx = _empty((M, K), torch.float32, x) if ctx.needs_input_grad[0] else None
+        dw = _zeros((N, K), torch.float32, x) if ctx.needs_input_grad[1] else None
+        db = _zeros((N,), torch.float32, x) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        call("dm_linear_bwd", ptr(x), ptr(w.contiguous()), ptr(g), ptr(dx), ptr(dw), ptr(db), M, K, N)
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    """x (..., K) fp32 -> (..., N); w may be a 1x1-conv weight (N, K, 1, 1)."""
+    w2 = w.reshape(w.shape[0], -1) if w.dim() == 4 else w
+    lead = x.shape[:-1]
+    y = Linear.apply(x.reshape(-1, x.shape[-1]), w2, b)
+    return y.reshape(*lead, w2.shape[0])
+
+
+class Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        L.require_device(x)
+        x = x.contiguous()
+        y = _empty(x.shape, torch.float32, x)
+        call("dm_act_fwd", ptr(x), ptr(y), x.numel(), act)
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        dx = _empty(x.shape, torch.float32, x)
+        call("dm_act_bwd", ptr(x), ptr(g.contiguous()), ptr(dx), x.numel(), ctx.act)
+        return dx, None
+
+
+class BnActMatrix(torch.autograd.Function):
+    """BatchNorm (+act) over the rows of an fp32 [M][C] matrix — CoordAttn's bn1_h / bn1_w on strips."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, bn, spec, act):
+        L.require_device(z)
+        shape = z.shape
+        z = z.contiguous().reshape(-1, shape[-1])
+        M, Cc = z.shape
+        mean, rstd = _empty((Cc,), torch.float32, z), _empty((Cc,), torch.float32, z)
+        train = bn.training
+        if train:
+            nblk = L.colstat_blocks(M)
+            p1, p2 = _empty((nblk, Cc), torch.float32, z), _empty((nblk, Cc), torch.float32, z)
+            call("dm_col_stats", ptr(z), L.DM_F32, M, Cc, ptr(p1), ptr(p2))
+            call("dm_bn_finalize", ptr(p1), ptr(p2), nblk, M, Cc, BN_EPS, bn.momentum, ptr(mean), ptr(rstd), ptr(bn.running_mean),
+                 ptr(bn.running_var))
+            spec.nbt_pending += 1
+        else:
+            call("dm_bn_fold", ptr(torch.ones_like(mean)), ptr(torch.zeros_like(mean)), ptr(torch.zeros_like(mean)),
+                 ptr(bn.running_var), None, BN_EPS, Cc, ptr(rstd), ptr(mean))
+            mean = bn.running_mean.clone()
+        y = _empty(z.shape, torch.float32, z)
+        call("dm_bn_act_fwd", ptr(z), ptr(y), L.DM_F32, M, Cc, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act)
+        ctx.save_for_backward(z, mean, rstd, gamma, beta)
+        ctx.meta = (train, act, shape)
+        return y.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        z, mean, rstd, gamma, beta = ctx.saved_tensors
+        train, act, shape = ctx.meta
+        M, Cc = z.shape
+        g = g.contiguous().reshape(M, Cc)
+        nblk = L.colstat_blocks(M)
+        p1, p2 = _empty((nblk, Cc), torch.float32, z), _empty((nblk, Cc), torch.float32, z)
+        call("dm_bn_act_bwd_reduce", ptr(z), ptr(g), L.DM_F32, M, Cc, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(p1), ptr(p2))
+        dbeta, dgamma = _empty((Cc,), torch.float32, z), _empty((Cc,), torch.float32, z)
+        call("dm_col_reduce", ptr(p1), nblk, Cc, ptr(dbeta), 0)
+        call("dm_col_reduce", ptr(p2), nblk, Cc, ptr(dgamma), 0)
+        dz = _empty(z.shape, torch.float32, z)
+        s1, s2 = (dbeta, dgamma) if train else (_zeros((Cc,), torch.float32, z),) * 2
+        call("dm_bn_act_bwd_apply", ptr(z), ptr(g), ptr(dz), L.DM_F32, M, Cc, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act,
+             ptr(s1), ptr(s2))
+        return dz.reshape(shape), dgamma, dbeta, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# SE + residual combine (one node): out = (res + x2 * sigmoid(W2 gelu(W1 mean_hw(x2)))) / 1.414
+# ------------------------------------------------------------------------------------------------
+class SeResidual(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2, res, w1, w2, inv):
+        L.require_device(x2, res)
+        x2, res = x2.contiguous(), res.contiguous()
+        B, H, W, Cc = x2.shape
+        out = _empty(x2.shape, x2.dtype, x2)
+        if w1 is None:                      # MNIST block: no SE, plain residual
+            call("dm_scale_residual_fwd", ptr(x2), ptr(res), None, ptr(out), dt(x2), B, H * W, Cc, inv)
+            ctx.save_for_backward()
+            ctx.meta = (None, inv, x2.shape, x2.dtype)
+            return out
+        R = w1.shape[0]
+        y = _empty((B, Cc), torch.float32, x2)
+        call("dm_pool_hw", ptr(x2), dt(x2), B, H * W, Cc, ptr(y))
+        hid, gh = _empty((B, R), torch.float32, x2), _empty((B, R), torch.float32, x2)
+        logit, sg = _empty((B, Cc), torch.float32, x2), _empty((B, Cc), torch.float32, x2)
+        call("dm_linear_fwd", ptr(y), ptr(w1), None, ptr(hid), B, Cc, R, ACT_NONE)
+        call("dm_act_fwd", ptr(hid), ptr(gh), B * R, ACT_GELU)
+        call("dm_linear_fwd", ptr(gh), ptr(w2), None, ptr(logit), B, R, Cc, ACT_NONE)
+        call("dm_act_fwd", ptr(logit), ptr(sg), B * Cc, ACT_SIGMOID)
+        call("dm_scale_residual_fwd", ptr(x2), ptr(res), ptr(sg), ptr(out), dt(x2), B, H * W, Cc, inv)
+        ctx.save_for_backward(x2, y, hid, gh, logit, sg, w1, w2)
+        ctx.meta = (R, inv, x2.shape, x2.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        R, inv, shape, dtype = ctx.meta
+        B, H, W, Cc = shape
+        g = g.contiguous()
+        dx2, dres = _empty(shape, dtype, g), _empty(shape, dtype, g)
+        if R is None:
+            call("dm_scale_residual_bwd_apply", ptr(g), None, None, ptr(dx2), ptr(dres), dt(dtype), B, H * W, Cc, inv)
+            return dx2, dres, None, None, None
+        x2, y, hid, gh, logit, sg, w1, w2 = ctx.saved_tensors
+        f = lambda *s: _empty(s, torch.float32, g)
+        dsg, dlogit, dgh, dhid, dy = f(B, Cc), f(B, Cc), f(B, R), f(B, R), f(B, Cc)
+        dw1, dw2 = _zeros((R, Cc), torch.float32, g), _zeros((Cc, R), torch.float32, g)
+        call("dm_scale_residual_bwd_reduce", ptr(g), ptr(x2), dt(dtype), B, H * W, Cc, inv, ptr(dsg))
+        call("dm_act_bwd", ptr(logit), ptr(dsg), ptr(dlogit), B * Cc, ACT_SIGMOID)
+        call("dm_linear_bwd", ptr(gh), ptr(w2), ptr(dlogit), ptr(dgh), ptr(dw2), None, B, R, Cc)
+        call("dm_act_bwd", ptr(hid), ptr(dgh), ptr(dhid), B * R, ACT_GELU)
+        call("dm_linear_bwd", ptr(y), ptr(w1), ptr(dhid), ptr(dy), ptr(dw1), None, B, Cc, R)
+        call("dm_scale_residual_bwd_apply", ptr(g), ptr(sg), ptr(dy), ptr(dx2), ptr(dres), dt(dtype), B, H * W, Cc, inv)
+        return dx2, dres, dw1, dw2, None
+
+
+# ------------------------------------------------------------------------------------------------
+# Coordinate attention pieces
+# ------------------------------------------------------------------------------------------------
+class PoolStrips(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        L.require_device(x)
+        x = x.contiguous()
+        B, H, W, Cc = x.shape
+        xh, xw = _empty((B, H, Cc), torch.float32, x), _empty((B, W, Cc), torch.float32, x)
+        call("dm_ca_pool_fwd", ptr(x), dt(x), B, H, W, Cc, ptr(xh), ptr(xw))
+        ctx.meta = (x.shape, x.dtype)
+        return xh, xw
+
+    @staticmethod
+    def backward(ctx, gh, gw):
+        shape, dtype = ctx.meta
+        B, H, W, Cc = shape
+        dx = _empty(shape, dtype, gh)
+        call("dm_ca_pool_bwd", ptr(gh.contiguous()), ptr(gw.contiguous()), None, ptr(dx), dt(dtype), B, H, W, Cc)
+        return dx
+
+
+class SigMix(torch.autograd.Function):
+    """xo = x + sigmoid(gamma) * y  (new_scripy.py:122-126)"""
+
+    @staticmethod
+    def forward(ctx, x, y, gamma):
+        x, y = x.contiguous(), y.contiguous()
+        xo = _empty(x.shape, torch.float32, x)
+        call("dm_sigmix_fwd", ptr(x), ptr(y), ptr(gamma), ptr(xo), x.numel())
+        ctx.save_for_backward(y, gamma)
+        return xo
+
+    @staticmethod
+    def backward(ctx, g):
+        y, gamma = ctx.saved_tensors
+        g = g.contiguous()
+        dy = _empty(y.shape, torch.float32, y)
+        dgamma = _zeros((1,), torch.float32, y)
+        call("dm_sigmix_bwd", ptr(g), ptr(y), ptr(gamma), ptr(dy), ptr(dgamma), y.numel())
+        return g, dy, dgamma
+
+
+class CaGate(torch.autograd.Function):
+    """out = x * (al*sigmoid(lh) + be*sigmoid(lw)) with al/be the normalised sigmoid(alpha/beta) (new_scripy.py:128-140)"""
+
+    @staticmethod
+    def forward(ctx, x, lh, lw, alpha, beta):
+        x, lh, lw = x.contiguous(), lh.contiguous(), lw.contiguous()
+        B, H, W, Cc = x.shape
+        out = _empty(x.shape, x.dtype, x)
+        call("dm_ca_gate_fwd", ptr(x), ptr(lh), ptr(lw), ptr(alpha), ptr(beta), ptr(out), dt(x), B, H, W, Cc)
+        ctx.save_for_backward(x, lh, lw, alpha, beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, lh, lw, alpha, beta = ctx.saved_tensors
+        B, H, W, Cc = x.shape
+        g = g.contiguous()
+        dx = _empty(x.shape, x.dtype, x)
+        dlh, dlw = _empty(lh.shape, torch.float32, x), _empty(lw.shape, torch.float32, x)
+        dab = _zeros((4,), torch.float32, x)
+        call("dm_ca_gate_bwd", ptr(x), ptr(g), ptr(lh), ptr(lw), ptr(alpha), ptr(beta), ptr(dx), ptr(dlh), ptr(dlw), ptr(dab), dt(x),
+             B, H, W, Cc)
+        return dx, dlh, dlw, dab[0:1], dab[1:2]
+
+
+# ------------------------------------------------------------------------------------------------
+# glue
+# ------------------------------------------------------------------------------------------------
+class UpCat(torch.autograd.Function):
+    """bilinear x2 (align_corners=True) of cat(x1, x2) (new_scripy.py:242,251)"""
+
+    @staticmethod
+    def forward(ctx, x1, x2):
+        L.require_device(x1, x2)
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        B, H, W, C1 = x1.shape
+        C2 = x2.shape[3]
+        y = _empty((B, 2 * H, 2 * W, C1 + C2), x1.dtype, x1)
+        call("dm_upcat_fwd", ptr(x1), ptr(x2), ptr(y), dt(x1), B, H, W, C1, C2)
+        ctx.meta = (B, H, W, C1, C2, x1.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, C1, C2, dtype = ctx.meta
+        g = g.contiguous()
+        d1, d2 = _empty((B, H, W, C1), dtype, g), _empty((B, H, W, C2), dtype, g)
+        call("dm_upcat_bwd", ptr(g), ptr(d1), ptr(d2), dt(dtype), B, H, W, C1, C2)
+        return d1, d2
+
+
+class Cat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2):
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        B, H, W, C1 = x1.shape
+        C2 = x2.shape[3]
+        y = _empty((B, H, W, C1 + C2), x1.dtype, x1)
+        call("dm_cat_fwd", ptr(x1), ptr(x2), ptr(y), dt(x1), B * H * W, C1, C2)
+        ctx.meta = (B, H, W, C1, C2, x1.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, C1, C2, dtype = ctx.meta
+        g = g.contiguous()
+        d1, d2 = _empty((B, H, W, C1), dtype, g), _empty((B, H, W, C2), dtype, g)
+        call("dm_cat_bwd", ptr(g), ptr(d1), ptr(d2), dt(dtype), B * H * W, C1, C2)
+        return d1, d2
+
+
+class Film(torch.autograd.Function):
+    """y = cemb[b,c] * x + temb[b,c] (new_scripy.py:348-349)"""
+
+    @staticmethod
+    def forward(ctx, x, cemb, temb):
+        x, cemb, temb = x.contiguous(), cemb.contiguous(), temb.contiguous()
+        B, H, W, Cc = x.shape
+        y = _empty(x.shape, x.dtype, x)
+        call("dm_film_fwd", ptr(x), ptr(cemb), ptr(temb), ptr(y), dt(x), B, H * W, Cc)
+        ctx.save_for_backward(x, cemb)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, cemb = ctx.saved_tensors
+        B, H, W, Cc = x.shape
+        g = g.contiguous()
+        dx = _empty(x.shape, x.dtype, x)
+        dce, dte = _empty((B, Cc), torch.float32, x), _empty((B, Cc), torch.float32, x)
+        call("dm_film_bwd", ptr(x), ptr(g), ptr(cemb), ptr(dx), ptr(dce), ptr(dte), dt(x), B, H * W, Cc)
+        return dx, dce, dte
+
+
+class AvgPoolGelu(torch.autograd.Function):
+    """AvgPool2d(k) + GELU -> fp32 (new_scripy.py:290)"""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        x = x.contiguous()
+        B, H, W, Cc = x.shape
+        y = _empty((B, H // k, W // k, Cc), torch.float32, x)
+        call("dm_avgpool_gelu_fwd", ptr(x), ptr(y), dt(x), B, H, W, Cc, k)
+        ctx.save_for_backward(x)
+        ctx.k = k
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        B, H, W, Cc = x.shape
+        if H % ctx.k or W % ctx.k:
+            raise L.DmError("avgpool backward needs H, W divisible by k")
+        dx = _empty(x.shape, x.dtype, x)
+        call("dm_avgpool_gelu_bwd", ptr(x), ptr(g.contiguous()), ptr(dx), dt(x), B, H, W, Cc, ctx.k)
+        return dx, None
+
+
+class MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, H, W, Cc = x.shape
+        y = _empty((B, H // 2, W // 2, Cc), x.dtype, x)
+        call("dm_maxpool2_fwd", ptr(x), ptr(y), dt(x), B, H, W, Cc)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        B, H, W, Cc = x.shape
+        dx = _empty(x.shape, x.dtype, x)
+        call("dm_maxpool2_bwd", ptr(x), ptr(g.contiguous()), ptr(dx), dt(x), B, H, W, Cc)
+        return dx
+
+
+def onehot_mask(c, mask, n_classes, flip=False):
+    L.require_device(c, mask)
+    B = c.shape[0]
+    out = _empty((B, n_classes), torch.float32, mask)
+    call("dm_onehot_mask", ptr(c.contiguous()), ptr(mask.contiguous()), ptr(out), B, n_classes, int(flip))
+    return out
+
+
+def nchw_to_nhwc(x, dtype, cp, repeat=1):
+    L.require_device(x)
+    B, Cc, H, W = x.shape
+    y = _empty((B * repeat, H, W, cp), dtype, x)
+    call("dm_nchw_to_nhwc", ptr(x.contiguous()), ptr(y), dt(dtype), B, Cc, H, W, cp, repeat)
+    return y
+
+
+def nhwc_to_nchw(x, c):
+    B, H, W, Cp = x.shape
+    y = _empty((B, c, H, W), torch.float32, x)
+    call("dm_nhwc_to_nchw", ptr(x.contiguous()), ptr(y), dt(x), B, c, H, W, Cp)
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# DDPM pieces
+# ------------------------------------------------------------------------------------------------
+def qsample(x, noise, ts, sqrtab, sqrtmab, dtype, cp):
+    L.require_device(x, noise, ts)
+    B, Cc, H, W = x.shape
+    xt = _empty((B, H, W, cp), dtype, x)
+    call("dm_qsample", ptr(x.contiguous()), ptr(noise.contiguous()), ptr(ts.contiguous()), ptr(sqrtab), ptr(sqrtmab), ptr(xt), dt(dtype),
+         B, Cc, H, W, cp)
+    return xt
+
+
+class WeightedLoss(torch.autograd.Function):
+    """mean(w*(n-p)^2) + feat_w*mean(|p*h - n*h|)  (new_scripy.py:417-437); mask None -> plain MSE (MNIST_script.py:252)"""
+
+    @staticmethod
+    def forward(ctx, pred, noise, mask, cfg6):
+        L.require_device(pred, noise)
+        pred, noise = pred.contiguous(), noise.contiguous()
+        B, Cc, H, W = pred.shape
+        loss = _zeros((1,), torch.float32, pred)
+        call("dm_loss_fwd", ptr(pred), ptr(noise), ptr(mask), ptr(cfg6), ptr(loss), B, Cc, H, W)
+        ctx.save_for_backward(pred, noise, mask, cfg6)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, noise, mask, cfg6 = ctx.saved_tensors
+        B, Cc, H, W = pred.shape
+        dpred = _empty(pred.shape, torch.float32, pred)
+        gs = g.reshape(1).float().contiguous()
+        call("dm_loss_bwd", ptr(pred), ptr(noise), ptr(mask), ptr(cfg6), ptr(gs), ptr(dpred), L.DM_F32, B, Cc, H, W, 0)
+        return dpred, None, None, None
+
+
+def cfg_update(x, eps2n, z, guide_w, sched, step, seed=0, dec_step=True):
+    """In-place x_{t-1} update (new_scripy.py:468-475); `step` is a device int32 tensor holding i."""
+    call("dm_cfg_update", ptr(x), ptr(eps2n), ptr(z), float(guide_w), ptr(sched["oneover_sqrta"]), ptr(sched["mab_over_sqrtmab"]),
+         ptr(sched["sqrt_beta_t"]), ptr(step), int(seed), x.numel(), int(dec_step))
+
+
+def fill_t(t, step, n_T):
+    call("dm_fill_t", ptr(t), ptr(step), int(n_T), t.numel())
+
+
+def randn(shape, device, seed, offset):
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    call("dm_randn", ptr(out), out.numel(), int(seed), int(offset))
+    return out
+
+
+class MaskAxpy(torch.autograd.Function):
+    """out = x + y * [mask > thresh]  (LocalEnhancer, new_scripy.py:172-174); mask (B,H,W) fp32"""
+
+    @staticmethod
+    def forward(ctx, x, y, mask, thresh):
+        x, y = x.contiguous(), y.contiguous()
+        B, H, W, Cc = x.shape
+        out = _empty(x.shape, x.dtype, x)
+        call("dm_mask_axpy", ptr(x), ptr(y), ptr(mask), thresh, ptr(out), dt(x), B * H * W, Cc)
+        ctx.save_for_backward(mask)
+        ctx.thresh = thresh
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        g = g.contiguous()
+        B, H, W, Cc = g.shape
+        dy = _empty(g.shape, g.dtype, g)
+        call("dm_mask_axpy", None, ptr(g), ptr(mask), ctx.thresh, ptr(dy), dt(g), B * H * W, Cc)
+        return g, dy, None, None

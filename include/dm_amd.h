@@ -182,6 +182,8 @@ int dm_avgpool_gelu_bwd(const void* x, const float* dy, void* dx, int dtype, int
 /* MaxPool2d(2) (MNIST_script.py:74) */
 int dm_maxpool2_fwd(const void* x, void* y, int dtype, int B, int H, int W, int C, dm_stream_t s);
 int dm_maxpool2_bwd(const void* x, const void* dy, void* dx, int dtype, int B, int H, int W, int C, dm_stream_t s);
+/* out = (x ? x : 0) + y * [mask[b,pix] > thresh]  (LocalEnhancer, new_scripy.py:172-174; x may be NULL) */
+int dm_mask_axpy(const void* x, const void* y, const float* mask, float thresh, void* out, int dtype, int64_t npix, int C, dm_stream_t s);
 /* y = a + b (skip-connection gradient joins) */
 int dm_add(const void* a, const void* b, void* y, int dtype, int64_t n, dm_stream_t s);
 
@@ -219,6 +221,10 @@ int dm_sumsq(const float* g, int64_t n, float* out /* one float, += */, dm_strea
 /* clip coefficient = min(1, max_norm/(sqrt(*sumsq)*gscale + 1e-6)); gscale folds 1/world etc.
  * hyper = {lr, beta1, beta2, eps, weight_decay, max_norm, gscale, bias_corr1, bias_corr2} (device) */
 int dm_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hyper9, dm_stream_t s);
+
+/* multi-tensor fp32 copy/add: table_dev[e] = {src_ptr, dst_ptr, count}; gathers the small parameters'
+ * gradients into the flat gradient buffer in one launch */
+int dm_scatter_copy(const int64_t* table_dev, int n_entries, int add, dm_stream_t s);
 
 #ifdef __cplusplus
 }

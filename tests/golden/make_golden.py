@@ -84,7 +84,7 @@ def gen_modules(R):
     run_module("rcb_3_16_res", R.ResConvBlock(3, 16, True), {"x": si("rcb_3_16_res.x", (2, 3, 16, 16))})
     run_module("rcb_16_16_res", R.ResConvBlock(16, 16, True), {"x": si("rcb_16_16_res.x", (2, 16, 16, 16))})
     run_module("rcb_16_16_plain", R.ResConvBlock(16, 16, False), {"x": si("rcb_16_16_plain.x", (2, 16, 16, 16))})
-    run_module("down_16_32", R.UnetDown(16, 32), {"x": si("down_16_32.x", (2, 16, 16, 16))})
+    run_module("down_32_64", R.UnetDown(32, 64), {"x": si("down_32_64.x", (2, 32, 16, 16))})
     run_module("up_64_16", R.UnetUp(64, 16), {"x": si("up_64_16.x", (2, 32, 8, 8)), "skip": si("up_64_16.skip", (2, 32, 8, 8))})
     run_module("fc_1_32", R.EmbedFC(1, 32), {"x": si("fc_1_32.x", (5, 1))})
     run_module("fc_4_32", R.EmbedFC(4, 32), {"x": si("fc_4_32.x", (5, 4))})
@@ -109,7 +109,7 @@ def child_grad_norms(net):
     return d
 
 
-def gen_unet(R, tag, S, k, nf=16, ncls=4, B=2):
+def gen_unet(R, tag, S, k, nf=32, ncls=4, B=2):
     net = make_ref_unet(R, nf, ncls, k)
     SCHEMA[tag] = load_synth(net)
     init = {kk: v.clone() for kk, v in net.state_dict().items()}
@@ -173,7 +173,7 @@ class Inject:
         return synth.synth_noise(f"{self.tag}.z{self.n - 1}", tuple(shape))
 
 
-def gen_ddpm_forward(R, tag="ddpm_fwd64", S=64, k=4, nf=16, ncls=4, B=4, n_T=1000):
+def gen_ddpm_forward(R, tag="ddpm_fwd64", S=64, k=4, nf=32, ncls=4, B=4, n_T=1000):
     net = make_ref_unet(R, nf, ncls, k)
     ddpm = R.DDPM(net, (1e-4, 0.02), n_T, "cpu", drop_prob=0.1)
     SCHEMA[tag] = load_synth(ddpm)   # includes the 7 schedule buffers -> overwritten by synth! restore:
@@ -205,7 +205,7 @@ def gen_ddpm_forward(R, tag="ddpm_fwd64", S=64, k=4, nf=16, ncls=4, B=4, n_T=100
     print(tag, out['train.loss'], out['eval.loss'], out['ts'])
 
 
-def gen_ddpm_sample(R, tag, S, k, n_T, n, guide_w, nf=16, ncls=4):
+def gen_ddpm_sample(R, tag, S, k, n_T, n, guide_w, nf=32, ncls=4):
     net = make_ref_unet(R, nf, ncls, k)
     ddpm = R.DDPM(net, (1e-4, 0.02), n_T, "cpu", drop_prob=0.0)
     load_synth(ddpm)
@@ -269,15 +269,15 @@ def main():
     M = _refload.load("MNIST_script")
     gen_schedules(R)
     gen_modules(R)
-    gen_unet(R, "unet16_64", 64, 4)
-    gen_unet(R, "unet16_128", 128, 8)
+    gen_unet(R, "unet32_64", 64, 4)
+    gen_unet(R, "unet32_128", 128, 8)
     gen_ddpm_forward(R)
     gen_ddpm_sample(R, "sample64_T5", 64, 4, 5, 4, 2.0)
     gen_ddpm_sample(R, "sample64_T3_w0", 64, 4, 3, 8, 0.0)
     gen_mnist(M)
     # key schema of the full-size nets (shapes only; no tensors are instantiated for the big ones)
-    SCHEMA["ddpm_keys_F16_k4"] = [(k, list(v.shape)) for k, v in
-                                  R.DDPM(make_ref_unet(R, 16, 4, 4), (1e-4, 0.02), 1000, "cpu").state_dict().items()]
+    SCHEMA["ddpm_keys_F32_k4"] = [(k, list(v.shape)) for k, v in
+                                  R.DDPM(make_ref_unet(R, 32, 4, 4), (1e-4, 0.02), 1000, "cpu").state_dict().items()]
     SCHEMA["unet_keys_F32_k8_c10"] = [(k, list(v.shape)) for k, v in R.ContextUnet(3, 32, 10).state_dict().items()]
     SCHEMA["mnist_keys_F32"] = [(k, list(v.shape)) for k, v in M.ContextUnet(1, 32, 10).state_dict().items()]
     SCHEMA["cfg"] = {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(R.Cfg).items() if k.isupper()}

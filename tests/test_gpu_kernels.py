@@ -1,0 +1,395 @@
+"""Kernel-level parity on a real MI355X: every C-ABI family against a plain PyTorch fp32 (CPU) statement
+of the same op.  fp32 mode must agree to fp32 rounding; bf16 mode to bf16 rounding (tolerances stated
+per test).  Exact-integer data is used where a layout bug could hide behind smooth data."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    torch.manual_seed(0)
+
+
+def ops():
+    from diffusionmodel_amd import ops as o
+    return o
+
+
+def nhwc(x, dtype=torch.float32):
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+
+
+def nchw(y):
+    return y.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rel_err(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-12)).item()
+
+
+class Holder:
+    def __init__(self, w, b):
+        self.weight = torch.nn.Parameter(w.to(DEV).contiguous(memory_format=torch.channels_last) if w.dim() == 4 else w.to(DEV))
+        self.bias = torch.nn.Parameter(b.to(DEV)) if b is not None else None
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, W, k, stride, pad
+    (2, 32, 32, 8, 8, 3, 1, 1),
+    (3, 16, 64, 5, 7, 3, 1, 1),          # ragged M (105 rows), non-square
+    (2, 64, 136, 16, 16, 3, 1, 1),       # N not a multiple of the tile
+    (2, 32, 8, 12, 12, 1, 1, 0),         # 1x1, tiny N
+    (2, 32, 32, 16, 16, 4, 2, 1),        # 4x4 stride 2
+    (1, 256, 128, 4, 4, 3, 1, 1),        # deep / small spatial
+    (2, 8, 16, 6, 6, 3, 1, 1),           # C smaller than one k-step
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_forward_backward(case, dtype):
+    o = ops()
+    B, Ci, Co, H, W, k, s, p = case
+    x = torch.randn(B, Ci, H, W)
+    w = torch.randn(Co, Ci, k, k) / math.sqrt(Ci * k * k)
+    b = torch.randn(Co) * 0.1
+    if dtype == torch.bfloat16:      # make inputs exactly representable so only accumulation order differs
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, stride=s, padding=p)
+    probe = torch.randn_like(yr)
+    if dtype == torch.bfloat16:
+        probe = probe.bfloat16().float()
+    (yr * probe).sum().backward()
+
+    conv = Holder(w, b)
+    spec = o.ConvSpec(k, k, s, p)
+    xd = nhwc(x, dtype).requires_grad_(True)
+    y = o.conv_bn_act(xd, None, conv, None, spec)
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    assert rel_err(nchw(y), yr.detach()) < tol
+    (y.float() * nhwc(probe)).sum().backward()
+    gtol = 5e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(nchw(xd.grad), xr.grad) < gtol, "dgrad"
+    assert rel_err(conv.weight.grad.cpu(), wr.grad) < gtol, "wgrad"
+    assert rel_err(conv.bias.grad.cpu(), br.grad) < gtol, "bias grad"
+
+
+def test_wgrad_bf16_exact_integers():
+    """Small-integer data makes the bf16 weight gradient exact: any mistake in the transposed LDS read
+    (ds_read_b64_tr_b16 lane/row mapping) or in the pixel<->k assignment shows up as an O(1) error."""
+    o = ops()
+    B, Ci, Co, H, W = 2, 16, 24, 6, 5
+    x = torch.randint(-3, 4, (B, Ci, H, W)).float()
+    g = torch.randint(-2, 3, (B, Co, H, W)).float()
+    w = torch.randint(-2, 3, (Co, Ci, 3, 3)).float()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    (F.conv2d(xr, wr, None, padding=1) * g).sum().backward()
+    conv = Holder(w, torch.zeros(Co))
+    xd = nhwc(x, torch.bfloat16).requires_grad_(True)
+    y = o.conv_bn_act(xd, None, conv, None, o.ConvSpec(3, 3, 1, 1))
+    (y.float() * nhwc(g)).sum().backward()
+    assert torch.equal(conv.weight.grad.cpu(), wr.grad)
+    assert torch.equal(nchw(xd.grad), xr.grad)
+    assert torch.equal(conv.bias.grad.cpu(), g.sum((0, 2, 3)))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_concat_and_stem_pad_and_nchw_out(dtype):
+    o = ops()
+    B, H = 2, 8
+    # two-source (concat) input
+    x1, x2 = torch.randn(B, 16, H, H), torch.randn(B, 24, H, H)
+    w = torch.randn(32, 40, 3, 3) / 19
+    b = torch.randn(32) * 0.1
+    if dtype == torch.bfloat16:
+        x1, x2, w = x1.bfloat16().float(), x2.bfloat16().float(), w.bfloat16().float()
+    r1, r2, wr = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(torch.cat((r1, r2), 1), wr, b, padding=1)
+    probe = torch.randn_like(yr)
+    (yr * probe).sum().backward()
+    conv = Holder(w, b)
+    d1, d2 = nhwc(x1, dtype).requires_grad_(True), nhwc(x2, dtype).requires_grad_(True)
+    y = o.conv_bn_act(d1, d2, conv, None, o.ConvSpec(3, 3, 1, 1))
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(nchw(y), yr.detach()) < tol
+    (y.float() * nhwc(probe)).sum().backward()
+    assert rel_err(nchw(d1.grad), r1.grad) < tol and rel_err(nchw(d2.grad), r2.grad) < tol
+    assert rel_err(conv.weight.grad.cpu(), wr.grad) < tol
+    # stem: 3 real channels padded to 8; head: Cout = 3 written as NCHW fp32
+    xs = torch.randn(B, 3, H, H)
+    ws, wh = torch.randn(16, 3, 3, 3) / 5, torch.randn(3, 16, 3, 3) / 12
+    bs, bh = torch.randn(16) * 0.1, torch.randn(3) * 0.1
+    if dtype == torch.bfloat16:
+        xs, ws, wh = xs.bfloat16().float(), ws.bfloat16().float(), wh.bfloat16().float()
+    wsr, whr = ws.clone().requires_grad_(True), wh.clone().requires_grad_(True)
+    hr = F.conv2d(xs, wsr, bs, padding=1)
+    yr = F.conv2d(hr, whr, bh, padding=1)
+    probe = torch.randn_like(yr)
+    (yr * probe).sum().backward()
+    stem, head = Holder(ws, bs), Holder(wh, bh)
+    x8 = o.nchw_to_nhwc(xs.to(DEV), dtype, 8)
+    h = o.conv_bn_act(x8, None, stem, None, o.ConvSpec(3, 3, 1, 1))
+    y = o.conv_bn_act(h, None, head, None, o.ConvSpec(3, 3, 1, 1, out_nchw=True))
+    assert y.shape == (B, 3, H, H) and y.dtype == torch.float32
+    tol2 = 3e-5 if dtype == torch.float32 else 3e-2
+    assert rel_err(y.cpu(), yr.detach()) < tol2
+    (y * probe.to(DEV)).sum().backward()
+    assert rel_err(stem.weight.grad.cpu(), wsr.grad) < tol2
+    assert rel_err(head.weight.grad.cpu(), whr.grad) < tol2
+    assert rel_err(head.bias.grad.cpu(), probe.sum((0, 2, 3))) < tol2
+
+
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_bn_gelu(train, dtype):
+    o = ops()
+    B, Ci, Co, H = 4, 16, 32, 8
+    x = torch.randn(B, Ci, H, H)
+    conv_r = torch.nn.Conv2d(Ci, Co, 3, 1, 1)
+    bn_r = torch.nn.BatchNorm2d(Co)
+    with torch.no_grad():
+        bn_r.weight.uniform_(0.5, 1.5); bn_r.bias.uniform_(-0.3, 0.3)
+        bn_r.running_mean.uniform_(-0.2, 0.2); bn_r.running_var.uniform_(0.5, 1.5)
+    bn_d = torch.nn.BatchNorm2d(Co).to(DEV)
+    bn_d.load_state_dict(bn_r.state_dict())
+    conv_d = Holder(conv_r.weight.detach().clone(), conv_r.bias.detach().clone())
+    bn_r.train(train); bn_d.train(train)
+    xr = x.clone().requires_grad_(True)
+    yr = F.gelu(bn_r(conv_r(xr)))
+    probe = torch.randn_like(yr)
+    (yr * probe).sum().backward()
+    spec = o.ConvSpec(3, 3, 1, 1, o.ACT_GELU, bn_d)
+    xd = nhwc(x, dtype).requires_grad_(True)
+    y = o.conv_bn_act(xd, None, conv_d, bn_d, spec)
+    tol = 5e-5 if dtype == torch.float32 else 4e-2
+    assert rel_err(nchw(y), yr.detach()) < tol
+    (y.float() * nhwc(probe)).sum().backward()
+    assert rel_err(nchw(xd.grad), xr.grad) < tol * 4
+    assert rel_err(conv_d.weight.grad.cpu(), conv_r.weight.grad) < tol * 4
+    assert rel_err(bn_d.weight.grad.cpu(), bn_r.weight.grad) < tol * 4
+    assert rel_err(bn_d.bias.grad.cpu(), bn_r.bias.grad) < tol * 4
+    if train:
+        assert rel_err(bn_d.running_mean.cpu(), bn_r.running_mean) < 1e-5 + (0 if dtype == torch.float32 else 1e-2)
+        assert rel_err(bn_d.running_var.cpu(), bn_r.running_var) < 1e-5 + (0 if dtype == torch.float32 else 1e-2)
+    # eval-mode fused epilogue (no autograd)
+    if not train:
+        with torch.no_grad():
+            y2 = o.conv_bn_act(nhwc(x, dtype), None, conv_d, bn_d, spec)
+        assert rel_err(nchw(y2), yr.detach()) < tol
+
+
+@pytest.mark.parametrize("k,h", [(4, 1), (8, 1), (2, 7), (7, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_transpose(k, h, dtype):
+    o = ops()
+    B, Ci, Co = 3, 32, 16
+    ct = torch.nn.ConvTranspose2d(Ci, Co, k, k)
+    x = torch.randn(B, Ci, h, h)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+        with torch.no_grad():
+            ct.weight.copy_(ct.weight.bfloat16().float())
+    xr = x.clone().requires_grad_(True)
+    yr = ct(xr)
+    probe = torch.randn_like(yr)
+    (yr * probe).sum().backward()
+    hold = Holder(ct.weight.detach().clone(), ct.bias.detach().clone())
+    xd = nhwc(x, torch.float32).requires_grad_(True)     # fp32 input (the to_vec output), cast inside
+    y = o.ConvTransposeKS.apply(xd, hold.weight, hold.bias, dtype)
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(nchw(y), yr.detach()) < tol
+    (y.float() * nhwc(probe)).sum().backward()
+    assert rel_err(nchw(xd.grad), xr.grad) < tol * 2
+    assert rel_err(hold.weight.grad.cpu(), ct.weight.grad) < tol * 2
+    assert rel_err(hold.bias.grad.cpu(), ct.bias.grad) < tol * 2
+
+
+@pytest.mark.parametrize("act_name", ["relu", "gelu"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_groupnorm_act(act_name, dtype):
+    o = ops()
+    B, Cc, H = 3, 32, 6
+    gn = torch.nn.GroupNorm(8, Cc)
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5); gn.bias.uniform_(-0.3, 0.3)
+    x = torch.randn(B, Cc, H, H)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    f = F.relu if act_name == "relu" else F.gelu
+    yr = f(gn(xr))
+    probe = torch.randn_like(yr)
+    (yr * probe).sum().backward()
+    gw, gb = gn.weight.detach().clone().to(DEV).requires_grad_(True), gn.bias.detach().clone().to(DEV).requires_grad_(True)
+    xd = nhwc(x, dtype).requires_grad_(True)
+    y = o.GroupNormAct.apply(xd, gw, gb, 8, o.ACT_RELU if act_name == "relu" else o.ACT_GELU)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(nchw(y), yr.detach()) < tol
+    (y.float() * nhwc(probe)).sum().backward()
+    assert rel_err(nchw(xd.grad), xr.grad) < tol * 3
+    assert rel_err(gw.grad.cpu(), gn.weight.grad) < tol * 3
+    assert rel_err(gb.grad.cpu(), gn.bias.grad) < tol * 3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upcat_film_pool_glue(dtype):
+    o = ops()
+    B, H = 2, 5
+    a, b = torch.randn(B, 16, H, H), torch.randn(B, 8, H, H)
+    if dtype == torch.bfloat16:
+        a, b = a.bfloat16().float(), b.bfloat16().float()
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.interpolate(torch.cat((ar, br), 1), scale_factor=2, mode="bilinear", align_corners=True)
+    probe = torch.randn_like(yr)
+    (yr * probe).sum().backward()
+    ad, bd = nhwc(a, dtype).requires_grad_(True), nhwc(b, dtype).requires_grad_(True)
+    y = o.UpCat.apply(ad, bd)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(nchw(y), yr.detach()) < tol
+    (y.float() * nhwc(probe)).sum().backward()
+    assert rel_err(nchw(ad.grad), ar.grad) < tol * 2 and rel_err(nchw(bd.grad), br.grad) < tol * 2
+    # FiLM
+    ce, te = torch.randn(B, 16), torch.randn(B, 16)
+    cr, tr = ce.clone().requires_grad_(True), te.clone().requires_grad_(True)
+    ar2 = a.clone().requires_grad_(True)
+    yr = cr[:, :, None, None] * ar2 + tr[:, :, None, None]
+    probe = torch.randn_like(yr)
+    (yr * probe).sum().backward()
+    ad = nhwc(a, dtype).requires_grad_(True)
+    cd, td = ce.to(DEV).requires_grad_(True), te.to(DEV).requires_grad_(True)
+    y = o.Film.apply(ad, cd, td)
+    assert rel_err(nchw(y), yr.detach()) < tol
+    (y.float() * nhwc(probe)).sum().backward()
+    assert rel_err(nchw(ad.grad), ar2.grad) < tol * 2
+    assert rel_err(cd.grad.cpu(), cr.grad) < tol * 2 and rel_err(td.grad.cpu(), tr.grad) < tol * 2
+    # AvgPool k + GELU, MaxPool2, Cat
+    x = torch.randn(B, 16, 8, 8)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    yr = F.gelu(F.avg_pool2d(xr, 4))
+    probe = torch.randn_like(yr)
+    (yr * probe).sum().backward()
+    xd = nhwc(x, dtype).requires_grad_(True)
+    y = o.AvgPoolGelu.apply(xd, 4)
+    assert rel_err(nchw(y), yr.detach()) < tol
+    (y * nhwc(probe)).sum().backward()
+    assert rel_err(nchw(xd.grad), xr.grad) < tol * 2
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2)
+    probe = torch.randn_like(yr)
+    (yr * probe).sum().backward()
+    xd = nhwc(x, dtype).requires_grad_(True)
+    y = o.MaxPool2.apply(xd)
+    assert torch.equal(nchw(y), yr.detach())
+    (y.float() * nhwc(probe)).sum().backward()
+    assert rel_err(nchw(xd.grad), xr.grad) < tol
+    c1, c2 = nhwc(a, dtype).requires_grad_(True), nhwc(b, dtype).requires_grad_(True)
+    y = o.Cat.apply(c1, c2)
+    assert torch.equal(nchw(y), torch.cat((a, b), 1))
+    (y.float() * 2).sum().backward()
+    assert torch.all(c1.grad.float() == 2) and torch.all(c2.grad.float() == 2)
+
+
+def test_linear_act_and_small_gemm_shapes():
+    o = ops()
+    for (M, K, N) in [(5, 1, 32), (64, 4, 96), (130, 70, 33), (64, 256, 256)]:
+        x, w, b = torch.randn(M, K), torch.randn(N, K) / math.sqrt(K), torch.randn(N)
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        yr = F.gelu(F.linear(xr, wr, br))
+        probe = torch.randn_like(yr)
+        (yr * probe).sum().backward()
+        xd, wd, bd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        y = o.Act.apply(o.Linear.apply(xd, wd, bd), o.ACT_GELU)
+        assert rel_err(y.cpu(), yr.detach()) < 2e-5
+        (y * probe.to(DEV)).sum().backward()
+        assert rel_err(xd.grad.cpu(), xr.grad) < 5e-5
+        assert rel_err(wd.grad.cpu(), wr.grad) < 5e-5
+        assert rel_err(bd.grad.cpu(), br.grad) < 5e-5
+
+
+def test_loss_qsample_cfg_update_randn():
+    o = ops()
+    from oracle import unet_ref as O
+    B, Cc, S = 3, 3, 16
+    pred, noise = torch.randn(B, Cc, S, S), torch.randn(B, Cc, S, S)
+    mask = torch.full((B, S, S), 0.5)
+    mask[:, 8:] = 1.0
+    mask[:, 2:6, 3:9] = 3.0
+    pr = pred.clone().requires_grad_(True)
+    lr = O.weighted_loss(pr, noise, mask)
+    (lr * 0.25).backward()
+    cfg6 = torch.tensor([1.2, 0.8, 3.0, 1.0, 0.5, 2.0], device=DEV)
+    pd = pred.to(DEV).requires_grad_(True)
+    ld = o.WeightedLoss.apply(pd, noise.to(DEV), mask.to(DEV), cfg6)
+    assert abs(ld.item() - lr.item()) < 2e-6 * max(1, abs(lr.item()))
+    (ld * 0.25).backward()
+    assert rel_err(pd.grad.cpu(), pr.grad) < 1e-5
+    # plain MSE (MNIST)
+    pd2 = pred.to(DEV).requires_grad_(True)
+    l2 = o.WeightedLoss.apply(pd2, noise.to(DEV), None, None)
+    assert abs(l2.item() - F.mse_loss(pred, noise).item()) < 1e-5
+    l2.backward()
+    assert rel_err(pd2.grad.cpu(), 2 * (pred - noise) / pred.numel()) < 1e-5
+    # q-sample
+    sched = O.ddpm_schedules(1e-4, 0.02, 1000)
+    ts = torch.tensor([1, 500, 1000])
+    xt_r = O.q_sample(sched, pred, ts, noise)
+    xt = o.qsample(pred.to(DEV), noise.to(DEV), ts.to(DEV), sched["sqrtab"].to(DEV), sched["sqrtmab"].to(DEV), torch.float32, 8)
+    assert xt.shape == (B, S, S, 8)
+    assert torch.equal(xt[..., 3:].cpu(), torch.zeros(B, S, S, 5))
+    assert rel_err(nchw(xt[..., :3]), xt_r) < 1e-6
+    # cfg update: injected z, i > 1 and i == 1 (z ignored), then step counter decremented
+    n = 2
+    x = torch.randn(n, Cc, S, S)
+    eps = torch.randn(2 * n, Cc, S, S)
+    z = torch.randn(n, Cc, S, S)
+    sd = {k: v.to(DEV) for k, v in sched.items()}
+    for i in (1000, 2, 1):
+        step = torch.tensor([i], dtype=torch.int32, device=DEV)
+        xd = x.to(DEV).clone()
+        o.cfg_update(xd, eps.to(DEV), z.to(DEV), 2.0, sd, step)
+        xr = O.cfg_update(sched, i, x, eps[:n], eps[n:], 2.0, z if i > 1 else torch.zeros_like(z))
+        assert rel_err(xd.cpu(), xr) < 2e-6, i
+        assert int(step.item()) == i - 1
+    # Philox N(0,1): moments, determinism, offset independence
+    r1 = o.randn((1 << 20,), DEV, 1234, 7)
+    r2 = o.randn((1 << 20,), DEV, 1234, 7)
+    r3 = o.randn((1 << 20,), DEV, 1234, 8)
+    assert torch.equal(r1, r2) and not torch.equal(r1, r3)
+    assert abs(r1.mean().item()) < 5e-3 and abs(r1.std().item() - 1) < 5e-3
+    assert abs((r1 * r3).mean().item()) < 5e-3
+    assert abs((r1 ** 4).mean().item() - 3.0) < 0.05
+
+
+def test_fused_adamw_matches_torch():
+    from diffusionmodel_amd.optim import FusedAdamW
+    torch.manual_seed(1)
+    shapes = [(8, 4, 3, 3), (8,), (5, 7), (1,), (16, 8, 1, 1)]
+    ref = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    dev = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ref]
+    opt_r = torch.optim.AdamW(ref, lr=1e-2, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    opt_d = FusedAdamW(dev, lr=1e-2, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0)
+    for it in range(3):
+        grads = [torch.randn(s) * (3.0 if it == 0 else 0.05) for s in shapes]   # first step clips, later ones do not
+        for p, g in zip(ref, grads):
+            p.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        opt_r.step()
+        opt_d.zero_grad()
+        for p, g in zip(dev, grads):
+            p.grad = g.to(DEV)
+        opt_d.step()
+        for p, q in zip(ref, dev):
+            assert rel_err(q.detach().cpu(), p.detach()) < 2e-6, it

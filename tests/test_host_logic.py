@@ -1,0 +1,161 @@
+"""Host-side logic of the product package that needs no GPU: class surface, state_dict key schema vs. the
+reference's (recorded in tests/golden/schema.json), schedule tables, Cfg, loud failure without a device,
+bucket logic, and the 2-process gloo data-parallel path checked against the gradient-accumulation oracle."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import diffusionmodel_amd as D
+from diffusionmodel_amd import mnist as DM
+from diffusionmodel_amd import parallel
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+SCHEMA = json.load(open(os.path.join(G, "schema.json")))
+
+
+def shapes(sd):
+    return {k: tuple(v.shape) for k, v in sd.items()}
+
+
+def test_state_dict_schema_matches_reference():
+    net = D.ContextUnet(3, 32, 4, bottleneck_k=4)
+    assert shapes(net.state_dict()) == {k: tuple(s) for k, s in SCHEMA["unet32_64"]}
+    net = D.ContextUnet(3, 32, 10)       # reference default k = 8
+    assert shapes(net.state_dict()) == {k: tuple(s) for k, s in SCHEMA["unet_keys_F32_k8_c10"]}
+    m = DM.ContextUnet(1, 32, 10)
+    assert shapes(m.state_dict()) == {k: tuple(s) for k, s in SCHEMA["mnist_keys_F32"]}
+
+
+def test_ddpm_state_dict_schema_and_buffers():
+    ddpm = D.DDPM(D.ContextUnet(3, 32, 4, bottleneck_k=4), (1e-4, 0.02), 1000, "cpu")
+    assert shapes(ddpm.state_dict()) == {k: tuple(s) for k, s in SCHEMA["ddpm_keys_F32_k4"]}
+    assert ddpm.n_T == 1000 and ddpm.n_classes == 4 and ddpm.drop_prob == 0.1
+    assert hasattr(ddpm, "scaler") and hasattr(ddpm, "loss_mse")
+
+
+def test_schedules_bit_identical_to_reference():
+    g = np.load(os.path.join(G, "schedules.npz"))
+    for T in (400, 700, 1000):
+        s = D.ddpm_schedules(1e-4, 0.02, T)
+        assert list(s) == list(D.SCHEDULE_KEYS)
+        for k in D.SCHEDULE_KEYS:
+            assert np.array_equal(s[k].numpy(), g[f"T{T}.{k}"]), (T, k)
+    with pytest.raises(AssertionError):
+        D.ddpm_schedules(0.5, 0.1, 10)
+
+
+def test_cfg_matches_reference_and_is_mutable():
+    ref = SCHEMA["cfg"]
+    for k, v in ref.items():
+        have = getattr(D.Cfg, k)
+        assert (list(have) if isinstance(have, tuple) else have) == v, k
+    assert D.Config is D.Cfg
+    assert D.Cfg.BOTTLENECK_K == 8 and D.Cfg.DTYPE == "float32"
+    old = D.Cfg.HIGH_WEIGHT
+    try:
+        D.Cfg.HIGH_WEIGHT = 5.0
+        assert D.Cfg.loss_constants()[2] == 5.0
+    finally:
+        D.Cfg.HIGH_WEIGHT = old
+
+
+def test_constructor_surface():
+    assert D.ResidualConvBlock is D.ResConvBlock
+    D.CoordAttn(32, reduction=16)
+    D.SEBlock(32, reduction=16)
+    D.LocalEnhancer(16, high_thresh=1.2)
+    D.ResConvBlock(3, 16, is_res=True)
+    D.UnetDown(32, 64, compress_ratio=4)
+    D.UnetUp(64, 16)
+    D.EmbedFC(4, 32)
+    DM.ResidualConvBlock(in_channels=1, out_channels=16, is_res=True)
+    DM.ContextUnet(in_channels=1, n_feat=16, n_classes=10)
+    with pytest.raises(D.DmError):
+        D.ContextUnet(3, 20, 4)          # n_feat % 32 != 0 is refused loudly, not emulated
+
+
+def test_conv_weights_are_channels_last_and_survive_load_state_dict():
+    net = D.ContextUnet(3, 32, 4, bottleneck_k=4)
+    w = net.down1.down[0].weight
+    assert w.is_contiguous(memory_format=torch.channels_last)
+    sd = {k: torch.randn_like(v) if v.is_floating_point() else v for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    assert net.down1.down[0].weight.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(net.down1.down[0].weight, sd["down1.down.0.weight"])
+
+
+def test_no_cpu_fallback():
+    net = D.ContextUnet(3, 32, 4, bottleneck_k=4)
+    x = torch.zeros(1, 3, 64, 64)
+    with pytest.raises(D.DmError):
+        net(x, torch.tensor([0]), torch.tensor([0.5]), torch.tensor([1.0]))
+    ddpm = D.DDPM(net, (1e-4, 0.02), 10, "cpu")
+    with pytest.raises(D.DmError):
+        ddpm(x, torch.tensor([0]), torch.zeros(1, 64, 64))
+
+
+def test_bucket_bounds_cover_exactly():
+    for total in (1, 1000, 1024, 5000, 106_500_000):
+        for nb in (1, 3, 4, 7):
+            b = parallel.bucket_bounds(total, nb)
+            assert b[0][0] == 0 and b[-1][1] == total and len(b) <= nb
+            assert all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+
+
+# ---- 2-process gloo test: rank == micro-batch, summed gradient == accumulation oracle -------------
+def _dp_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    torch.set_num_threads(2)
+    from oracle import synth, unet_ref as O
+    r, w, _ = parallel.init_from_env("gloo")
+    spec = O.mnist_unet_spec(1, 8, 10, 7)
+    P = {"nn_model." + k: (v.requires_grad_(True) if v.is_floating_point() and "running" not in k else v)
+         for k, v in synth.synth_state(spec).items()}
+    B = 2
+    x = synth.synth_input("dp.x", (world * B, 1, 28, 28))[rank * B:(rank + 1) * B]
+    c = torch.arange(world * B)[rank * B:(rank + 1) * B] % 10
+    ts = (torch.arange(world * B) * 37 % 400 + 1)[rank * B:(rank + 1) * B]
+    noise = synth.synth_noise("dp.n", (world * B, 1, 28, 28))[rank * B:(rank + 1) * B]
+    drop = torch.zeros(B)
+    loss = O.mnist_ddpm_loss(P, O.ddpm_schedules(1e-4, 0.02, 400), 400, x, c, ts, noise, drop, True) / world
+    loss.backward()
+    params = [v for v in P.values() if v.requires_grad]
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    red = parallel.GradReducer(flat, n_buckets=3)
+    red.all_reduce()
+    if rank == 0:
+        torch.save(flat, os.path.join(out_dir, "dp_flat.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_data_parallel_matches_accumulation(tmp_path):
+    import torch.multiprocessing as mp
+    from oracle import synth, unet_ref as O
+    world, port = 2, 29000 + os.getpid() % 2000
+    mp.spawn(_dp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    flat_dp = torch.load(os.path.join(str(tmp_path), "dp_flat.pt"))
+    # single-process gradient accumulation over the same two micro-batches (new_scripy.py:786, 795-803)
+    torch.set_num_threads(2)
+    spec = O.mnist_unet_spec(1, 8, 10, 7)
+    P = {"nn_model." + k: (v.requires_grad_(True) if v.is_floating_point() and "running" not in k else v)
+         for k, v in synth.synth_state(spec).items()}
+    B = 2
+    xa = synth.synth_input("dp.x", (world * B, 1, 28, 28))
+    na = synth.synth_noise("dp.n", (world * B, 1, 28, 28))
+    ca = torch.arange(world * B) % 10
+    tsa = torch.arange(world * B) * 37 % 400 + 1
+    sched = O.ddpm_schedules(1e-4, 0.02, 400)
+    init_bn = {k: v.clone() for k, v in P.items() if "running" in k or "num_batches" in k}
+    for r in range(world):
+        for k, v in init_bn.items():      # every rank starts from the same running statistics
+            P[k].copy_(v)
+        sl = slice(r * B, (r + 1) * B)
+        (O.mnist_ddpm_loss(P, sched, 400, xa[sl], ca[sl], tsa[sl], na[sl], torch.zeros(B), True) / world).backward()
+    flat_acc = torch.cat([v.grad.reshape(-1) for v in P.values() if v.requires_grad])
+    assert flat_dp.shape == flat_acc.shape
+    assert torch.allclose(flat_dp, flat_acc, rtol=1e-5, atol=1e-7), (flat_dp - flat_acc).abs().max()

@@ -50,17 +50,17 @@ def test_schedules_bit_exact():
 
 
 def test_key_schema_matches_reference():
-    spec = O.context_unet_spec(3, 16, 4, 4)
-    ref = {k: tuple(s) for k, s in SCHEMA["unet16_64"]}
+    spec = O.context_unet_spec(3, 32, 4, 4)
+    ref = {k: tuple(s) for k, s in SCHEMA["unet32_64"]}
     assert {k: tuple(v) for k, v in spec.items()} == ref
     spec = O.context_unet_spec(3, 32, 10, 8)
     assert {k: tuple(v) for k, v in spec.items()} == {k: tuple(s) for k, s in SCHEMA["unet_keys_F32_k8_c10"]}
     spec = O.mnist_unet_spec(1, 32, 10, 7)
     assert {k: tuple(v) for k, v in spec.items()} == {k: tuple(s) for k, s in SCHEMA["mnist_keys_F32"]}
-    ddpm = {k: tuple(s) for k, s in SCHEMA["ddpm_keys_F16_k4"]}
+    ddpm = {k: tuple(s) for k, s in SCHEMA["ddpm_keys_F32_k4"]}
     for k in O.SCHEDULE_KEYS:
         assert ddpm[k] == (1001,)
-    assert {k[len("nn_model."):] for k in ddpm if k.startswith("nn_model.")} == set(O.context_unet_spec(3, 16, 4, 4))
+    assert {k[len("nn_model."):] for k in ddpm if k.startswith("nn_model.")} == set(O.context_unet_spec(3, 32, 4, 4))
 
 
 MODULE_CASES = {
@@ -114,7 +114,7 @@ def test_res_conv_block(tag, cin, res):
 
 
 def test_unet_down():
-    _run_block("down_16_32", lambda P, i, tr: O.unet_down(i["x"], _strip(P, "m"), "m", tr), {"x": si("down_16_32.x", (2, 16, 16, 16))})
+    _run_block("down_32_64", lambda P, i, tr: O.unet_down(i["x"], _strip(P, "m"), "m", tr), {"x": si("down_32_64.x", (2, 32, 16, 16))})
 
 
 def test_unet_up():
@@ -141,7 +141,7 @@ def _child_norms(P):
     return {k: v ** 0.5 for k, v in d.items()}
 
 
-@pytest.mark.parametrize("tag,S", [("unet16_64", 64), ("unet16_128", 128)])
+@pytest.mark.parametrize("tag,S", [("unet32_64", 64), ("unet32_128", 128)])
 def test_context_unet_whole(tag, S):
     g = npz(tag)
     x = si(tag + ".x", (2, 3, S, S))
