@@ -149,8 +149,9 @@ __global__ void ca_gate_bwd_strip_kernel(const float* S, const float* l, const f
     float part = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float sg = sigmoid_f(l[i]);
-        dl[i] = mix * sg * (1.f - sg) * S[i];
-        part += sg * S[i];
+        const float sv = S[i];            // S and dl alias (in-place): read before the store
+        dl[i] = mix * sg * (1.f - sg) * sv;
+        part += sg * sv;
     }
     part = block_sum(part, red);
     if (threadIdx.x == 0) atomicAdd(dmix + which, part);

@@ -46,11 +46,17 @@ def _cl(w):
 
 
 def _cached(key, w, build):
-    k = (key, w.data_ptr(), w._version, _EPOCH[0])
-    hit = _CACHE.get(k)
+    """Derived-tensor cache that lives ON the parameter object (so it dies with it; a data_ptr-keyed
+    global cache would hand a new tensor at a recycled address somebody else's pack)."""
+    stamp = (w.data_ptr(), w._version, _EPOCH[0])
+    store = getattr(w, "_dm_cache", None)
+    if store is None or store[0] != stamp:
+        store = (stamp, {})
+        w._dm_cache = store
+    hit = store[1].get(key)
     if hit is None:
         hit = build()
-        _CACHE[k] = hit
+        store[1][key] = hit
     return hit
 
 
@@ -151,6 +157,14 @@ def _bn_eval_fold(spec, bias):
     return _cached(key, bn.weight, build)
 
 
+def _running_stats(bn, n):
+    """(mean, rstd) of an eval-mode BatchNorm from its running statistics (dm_bn_fold with gamma=1, beta=0)."""
+    ones, zeros = torch.ones_like(bn.running_var), torch.zeros_like(bn.running_var)
+    rstd, dummy = torch.empty_like(bn.running_var), torch.empty_like(bn.running_var)
+    call("dm_bn_fold", ptr(ones), ptr(zeros), ptr(zeros), ptr(bn.running_var), None, BN_EPS, n, ptr(rstd), ptr(dummy))
+    return bn.running_mean.clone(), rstd
+
+
 class ConvBnAct(torch.autograd.Function):
     """y = act(BN(conv(cat(x, x2)) + b)) as ONE autograd node.
 
@@ -216,9 +230,7 @@ class ConvBnAct(torch.autograd.Function):
             bn._stat_epoch = getattr(bn, "_stat_epoch", 0) + 1
         else:  # eval mode with autograd: normalise with the running statistics, unfused
             _conv_call(x, x2, ptr(wp), T * Cp, z, shift=b, **geom)
-            call("dm_bn_fold", ptr(torch.ones_like(mean)), ptr(torch.zeros_like(mean)), ptr(torch.zeros_like(mean)),
-                 ptr(bn.running_var), None, BN_EPS, N, ptr(rstd), ptr(mean))   # rstd = rsqrt(var+eps)
-            mean = bn.running_mean.clone()
+            mean, rstd = _running_stats(bn, N)
         out = _empty((B, Ho, Wo, N), dtype, x)
         call("dm_bn_act_fwd", ptr(z), ptr(out), dt(dtype), M, N, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), spec.act)
         ctx.train = train
@@ -506,9 +518,7 @@ class BnActMatrix(torch.autograd.Function):
                  ptr(bn.running_var))
             spec.nbt_pending += 1
         else:
-            call("dm_bn_fold", ptr(torch.ones_like(mean)), ptr(torch.zeros_like(mean)), ptr(torch.zeros_like(mean)),
-                 ptr(bn.running_var), None, BN_EPS, Cc, ptr(rstd), ptr(mean))
-            mean = bn.running_mean.clone()
+            mean, rstd = _running_stats(bn, Cc)
         y = _empty(z.shape, torch.float32, z)
         call("dm_bn_act_fwd", ptr(z), ptr(y), L.DM_F32, M, Cc, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act)
         ctx.save_for_backward(z, mean, rstd, gamma, beta)

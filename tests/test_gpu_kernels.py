@@ -393,3 +393,32 @@ def test_fused_adamw_matches_torch():
         opt_d.step()
         for p, q in zip(ref, dev):
             assert rel_err(q.detach().cpu(), p.detach()) < 2e-6, it
+
+
+@pytest.mark.parametrize("M,Cc", [(32, 4), (32, 8), (8, 16), (24, 2), (600, 12), (1100, 64)])
+@pytest.mark.parametrize("train", [True, False])
+def test_bn_act_matrix_strips(M, Cc, train):
+    """BatchNorm(+GELU) over the rows of small fp32 matrices (CoordAttn strips): vector and scalar column paths."""
+    o = ops()
+    bn_r = torch.nn.BatchNorm1d(Cc)
+    with torch.no_grad():
+        bn_r.weight.uniform_(0.5, 1.5); bn_r.bias.uniform_(-0.3, 0.3)
+        bn_r.running_mean.uniform_(-0.2, 0.2); bn_r.running_var.uniform_(0.5, 1.5)
+    bn_d = torch.nn.BatchNorm2d(Cc).to(DEV)
+    bn_d.load_state_dict(bn_r.state_dict())
+    bn_r.train(train); bn_d.train(train)
+    z = torch.randn(M, Cc) * 0.7 + 0.3
+    zr = z.clone().requires_grad_(True)
+    yr = F.gelu(bn_r(zr))
+    probe = torch.randn_like(yr)
+    (yr * probe).sum().backward()
+    zd = z.to(DEV).requires_grad_(True)
+    spec = o.ConvSpec(1, 1, 1, 0, o.ACT_GELU, bn_d)
+    y = o.BnActMatrix.apply(zd, bn_d.weight, bn_d.bias, bn_d, spec, o.ACT_GELU)
+    assert rel_err(y.cpu(), yr.detach()) < 1e-5
+    (y * probe.to(DEV)).sum().backward()
+    assert rel_err(zd.grad.cpu(), zr.grad) < 5e-5
+    assert rel_err(bn_d.weight.grad.cpu(), bn_r.weight.grad) < 5e-5
+    assert rel_err(bn_d.bias.grad.cpu(), bn_r.bias.grad) < 5e-5
+    if train:
+        assert rel_err(bn_d.running_var.cpu(), bn_r.running_var) < 1e-5

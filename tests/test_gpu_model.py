@@ -64,7 +64,7 @@ def run_block(tag, mod, inputs, tol=1e-4, gtol=2e-3):
         for k, p in mod.named_parameters():
             ref = g[f"{mode}.g.{k}"]
             got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(ref)
-            if np.abs(ref).max() < 1e-6:      # e.g. conv bias in front of BatchNorm: mathematically zero
+            if np.abs(ref).max() < 5e-5 and k.endswith(".bias"):   # conv bias in front of train-mode BatchNorm: mathematically zero, fp32 noise on both sides
                 assert np.abs(got).max() < 1e-4, (tag, mode, k)
             else:
                 assert relerr(got, ref) < gtol, (tag, mode, k, relerr(got, ref))
@@ -101,7 +101,7 @@ def test_res_conv_block(tag, cin, res):
             (y * si(tag + ".probe", tuple(y.shape)).to(DEV)).sum().backward()
             for k, p in mod.named_parameters():
                 ref = g[f"{mode}.g.{k}"]
-                if np.abs(ref).max() > 1e-6:
+                if not (np.abs(ref).max() < 5e-5 and k.endswith(".bias")):
                     assert relerr(p.grad.cpu().numpy(), ref) < 2e-3, (k, mode)
             mod.zero_grad()
         return
@@ -136,6 +136,29 @@ def _child_norms(net):
     return d
 
 
+_ORACLE_GRADS = {}
+
+
+def _oracle_train_grads(tag, S, x, c, t, mk):
+    """Train-mode parameter gradients of the CPU oracle in fp64 and fp32 (cached per fixture)."""
+    if tag not in _ORACLE_GRADS:
+        out = []
+        for dt_ in (torch.float64, torch.float32):
+            P = {}
+            for k_, s_ in SCHEMA[tag]:
+                v = synth.synth_tensor(k_, tuple(s_))
+                if v.is_floating_point():
+                    v = v.to(dt_)
+                    if "running" not in k_:
+                        v.requires_grad_(True)
+                P[k_] = v
+            eps = O.context_unet(P, x.to(dt_), c, t.to(dt_), mk.to(dt_), True)
+            (eps * si(tag + ".probe", tuple(eps.shape)).to(dt_)).mean().backward()
+            out.append({k_: v.grad.numpy() for k_, v in P.items() if v.is_floating_point() and v.grad is not None})
+        _ORACLE_GRADS[tag] = out
+    return _ORACLE_GRADS[tag]
+
+
 @pytest.mark.parametrize("tag,S,k", [("unet32_64", 64, 4), ("unet32_128", 128, 8)])
 def test_context_unet_vs_reference_fixture(tag, S, k):
     import diffusionmodel_amd as D
@@ -166,7 +189,14 @@ def test_context_unet_vs_reference_fixture(tag, S, k):
             if key.startswith(f"{mode}.g."):
                 pn = key.split(".", 2)[2]
                 got = dict(net.named_parameters())[pn].grad.cpu().numpy()
-                assert relerr(got, g[key]) < (5e-3 if train else 5e-4), (pn, relerr(got, g[key]))
+                if not train:
+                    assert relerr(got, g[key]) < 5e-4, (pn, relerr(got, g[key]))
+                else:
+                    # train-mode BatchNorm over B=2 amplifies fp32 rounding: measure the CPU oracle's own
+                    # fp32-vs-fp64 deviation for this parameter and allow a few times that
+                    g64, g32 = _oracle_train_grads(tag, S, x, c, t, mk)
+                    noise = relerr(g32[pn], g64[pn])
+                    assert relerr(got, g64[pn]) < max(5e-3, 4 * noise), (pn, relerr(got, g64[pn]), noise)
         if train:
             sd = net.state_dict()
             for key in g.files:
