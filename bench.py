@@ -158,9 +158,12 @@ def main():
     # ---- roofline of the dominant kernel family (implicit-GEMM conv fwd/dgrad + wgrad) from the events
     fl = {"conv_igemm": [0.0, 0.0, 0], "conv_wgrad": [0.0, 0.0, 0]}
     for (kind, flops, e0, e1) in prof:
+        fl.setdefault(kind, [0.0, 0.0, 0])
         fl[kind][0] += flops
         fl[kind][1] += e0.elapsed_time(e1) * 1e-3
         fl[kind][2] += 1
+    if dtype != torch.bfloat16:
+        fl["conv_igemm"], fl["conv_wgrad"] = fl.get("igemm_f32", [0.0, 0.0, 0]), fl.get("wgrad_f32", [0.0, 0.0, 0])
     dom = "conv_igemm"
     peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
     ach = fl[dom][0] / max(fl[dom][1], 1e-12) / 1e12

@@ -256,12 +256,17 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* A, const float*
     }
 }
 
-__global__ void colsum_small_kernel(const float* dy, float* db, int M, int N) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+// db[n] += sum_m dy[m][n]: block = 64 columns x 4 row lanes over a 256-row slab (grid.y), atomics across slabs
+__global__ __launch_bounds__(256) void colsum_small_kernel(const float* dy, float* db, int M, int N) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * 256, r1 = min(r0 + 256, M);
     float s = 0.f;
-    for (int m = 0; m < M; ++m) s += dy[(size_t)m * N + n];
-    db[n] += s;
+    if (n < N)
+        for (int m = r0 + rl; m < r1; m += 4) s += dy[(size_t)m * N + n];
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && n < N) atomicAdd(db + n, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 __global__ void act_fwd_kernel(const float* x, float* y, int n, int act) {
@@ -382,7 +387,7 @@ extern "C" int dm_linear_bwd(const float* x, const float* w, const float* dy, fl
         hipLaunchKernelGGL(sgemm_kernel, dim3(cdiv(K, 64), cdiv(M, 64)), dim3(256), 0, ST, dy, w, (const float*)nullptr, dx, M, K, N, (int64_t)N, (int64_t)1, (int64_t)K, (int64_t)1, K, 0, 0);
     if (dw)  // dw[n][k] += sum_m dy[m][n] x[m][k]
         hipLaunchKernelGGL(sgemm_kernel, dim3(cdiv(K, 64), cdiv(N, 64)), dim3(256), 0, ST, dy, x, (const float*)nullptr, dw, N, K, M, (int64_t)1, (int64_t)N, (int64_t)K, (int64_t)1, K, 0, 1);
-    if (db) hipLaunchKernelGGL(colsum_small_kernel, dim3(cdiv(N, 256)), dim3(256), 0, ST, dy, db, M, N);
+    if (db) hipLaunchKernelGGL(colsum_small_kernel, dim3(cdiv(N, 64), cdiv(M, 256)), dim3(256), 0, ST, dy, db, M, N);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

@@ -1,25 +1,33 @@
-// Implicit-GEMM gather convolution on the CDNA4 matrix cores (forward, input-gradient, ConvTranspose).
+// Implicit-GEMM gather convolution on the CDNA4 matrix cores (forward, input-gradient, ConvTranspose,
+// and — as a 1x1 "image" — the dense fp32 layers).
 //
 // One kernel serves every dense contraction of the denoiser (include/dm_amd.h, dm_conv): the output
 // tile is 128 output pixels x BN output channels per 256-thread workgroup (4 waves as 2(m) x 2(n)),
-// K runs over taps x input channels in steps of 64 bytes per row.  Both operands are staged through
-// LDS as [row][64 B] images with an XOR swizzle that makes the ds_read_b128 fragment reads
-// conflict-free (16-lane groups hit 16 distinct 16-B slots), register-prefetched one k-step ahead
-// and double buffered (one barrier per k-step).
+// K runs over taps x input channels in steps of 128 bytes per row (64 bf16 / 32 f32 channels).  Both
+// operands are staged through LDS as [row][128 B] images whose 16-byte vectors are XOR-swizzled with
+// the row index (vec ^= row & 7), which makes the ds_read_b128 fragment reads conflict-free (every
+// 16-lane group of the instruction hits 16 distinct 16-B slots of the 256-B bank row) while the
+// staging writes stay whole-row contiguous.  Global loads are register-prefetched one k-step ahead and
+// the LDS image is double buffered: one barrier per k-step, two MFMA k-sub-steps between barriers.
 //
 // MFMA orientation is "swapped": A operand = packed weights (row i = output channel), B operand =
 // gathered input pixels (column j = output pixel), so every lane ends up with 4 consecutive output
 // channels of one pixel -> one 8-byte (bf16) / 16-byte (f32) NHWC store per 16x16 tile.
 //   bf16: v_mfma_f32_16x16x32_bf16, a lane's fragment = 8 consecutive k of its row.
-//   f32 : v_mfma_f32_16x16x4_f32 x 4 per 16-B fragment; element j of the lane group g is k = 4g + j on
-//         both operands, so the four MFMAs together cover the 16 k of the step exactly once.
+//   f32 : v_mfma_f32_16x16x4_f32 x 4 per 16-B fragment; element j of lane group g is k = 4g + j on both
+//         operands, so the four MFMAs together cover the 16 k of the sub-step exactly once.
 //         (f32 MFMA is a k-ordered fmaf chain: exact fp32, which is what the 1e-4 parity mode needs.)
+//
+// Workgroup -> tile mapping is XCD-aware: the dispatcher deals consecutive workgroups round-robin over
+// the 8 XCDs, so tile = (bid % 8) * (ntiles / 8) + bid / 8 (bijective form) gives every XCD a contiguous
+// run of tiles — vertically adjacent image rows (shared 3x3 halo) and the n-tiles of one pixel block
+// then meet in the same 4 MiB L2.  Placement only affects speed, never results.
 #include "common.h"
 
 namespace {
 
 constexpr int BM = 128;
-constexpr int ROWB = 64;  // bytes per LDS row per k-step (4 x 16-B vectors)
+constexpr int ROWB = 128;  // bytes per LDS row per k-step (8 x 16-B vectors)
 
 struct ConvP {
     const char* in1; const char* in2; const char* w;
@@ -30,7 +38,7 @@ struct ConvP {
     int Ho, Wo, osy, osx, ooy, oox, N, ldw, ldc, coff, M;
 };
 
-__device__ inline int lds_off(int row, int vec) { return row * ROWB + ((vec ^ ((row >> 1) & 3)) << 4); }
+__device__ inline int lds_off(int row, int vec) { return row * ROWB + ((vec ^ (row & 7)) << 4); }
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
@@ -49,9 +57,9 @@ template <> struct Mma<float> {
 template <typename T, int BN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     constexpr int VE = Elem<T>::VE;
-    constexpr int BK = 4 * VE;
-    constexpr int NT = BN / 32;              // 16-wide channel tiles per wave
-    constexpr int BV = (BN * 4 + 255) / 256;  // weight vectors per thread per k-step
+    constexpr int BK = 8 * VE;                // channels per k-step
+    constexpr int NT = BN / 32;               // 16-wide channel tiles per wave
+    constexpr int BV = (BN * 8 + 255) / 256;  // weight vectors per thread per k-step
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     __shared__ __attribute__((aligned(16))) char smem[2 * (A_BYTES + B_BYTES)];
 
@@ -59,20 +67,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     const int wm = wave & 1, wn = wave >> 1;
     const int fr = lane & 15, fg = lane >> 4;
     const int nb_n = (p.N + BN - 1) / BN;
-    const int mb = blockIdx.x / nb_n, nb = blockIdx.x - mb * nb_n;
+    // XCD-aware remap of the linear workgroup id (bijective for any grid size)
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int mb = bid / nb_n, nb = bid - mb * nb_n;
     const int m0 = mb * BM, n0 = nb * BN;
     const int C = p.C1 + p.C2;
     const T* in1 = (const T*)p.in1;
     const T* in2 = (const T*)p.in2;
     const T* wgt = (const T*)p.w;
 
-    // ---- per-thread staging assignment: A rows (tid>>2) and +64, vector tid&3
-    const int sv = tid & 3;
-    int a_b[2], a_y[2], a_x[2];
-    bool a_ok[2];
+    // ---- per-thread staging assignment: A rows (tid>>3) + 32*i, vector tid&7
+    const int sv = tid & 7, srow = tid >> 3;
+    int a_b[4], a_y[4], a_x[4];
+    bool a_ok[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + (tid >> 2) + 64 * i;
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + srow + 32 * i;
         a_ok[i] = m < p.M;
         const int mm = a_ok[i] ? m : 0;
         const int qx = mm % p.Wq, tq = mm / p.Wq;
@@ -82,41 +96,52 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         a_x[i] = qx * p.sx + p.ox0;
     }
 
-    u32x4 ra[2], rb[BV];
-    auto gload = [&](int t, int c0) {
-        const int ky = t / p.KW, kx = t - ky * p.KW;
-        const int dy = ky * p.ty, dx = kx * p.tx;
-        const int c = c0 + sv * VE;
+    // one register set: global loads run one k-step ahead of the MFMAs (in registers on their way to LDS);
+    // a second workgroup on the CU covers the rest of the HBM/L2 latency
+    u32x4 ra0[4], rb0[BV];
+    // tap state of the NEXT load (advanced incrementally: no division in the loop)
+    int ld_t = 0, ld_ky = 0, ld_kx = 0, ld_c0 = 0;
+    auto gload = [&](u32x4 (&ra)[4], u32x4 (&rb)[BV]) {
+        const int dy = ld_ky * p.ty, dx = ld_kx * p.tx;
+        const int c = ld_c0 + sv * VE;
+        const bool c_ok = c < C;
+        const bool first = c < p.C1;
+        const T* src_base = first ? in1 : in2;
+        const int cs = first ? p.C1 : p.C2, cc = first ? c : c - p.C1;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int iy = a_y[i] + dy, ix = a_x[i] + dx;
-            const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && c < C;
+            const bool ok = a_ok[i] && c_ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (ok) {
                 const size_t pix = ((size_t)a_b[i] * p.Hi + iy) * p.Wi + ix;
-                const T* src = (c < p.C1) ? (in1 + pix * p.C1 + c) : (in2 + pix * p.C2 + (c - p.C1));
-                v = *(const u32x4*)src;
+                v = *(const u32x4*)(src_base + pix * cs + cc);
             }
             ra[i] = v;
         }
 #pragma unroll
         for (int j = 0; j < BV; ++j) {
-            const int idx = tid + 256 * j;
-            const int row = idx >> 2;
+            const int row = srow + 32 * j;
             const int n = n0 + row;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (row < BN && n < p.N && c < C) v = *(const u32x4*)(wgt + (size_t)n * p.ldw + (size_t)t * C + c);
+            if (row < BN && n < p.N && c_ok) v = *(const u32x4*)(wgt + (size_t)n * p.ldw + (size_t)ld_t * C + c);
             rb[j] = v;
         }
+        ld_c0 += BK;
+        if (ld_c0 >= C) {
+            ld_c0 = 0;
+            ++ld_t;
+            if (++ld_kx == p.KW) { ld_kx = 0; ++ld_ky; }
+        }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, const u32x4 (&ra)[4], const u32x4 (&rb)[BV]) {
         char* sA = smem + buf * (A_BYTES + B_BYTES);
         char* sB = sA + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *(u32x4*)(sA + lds_off((tid >> 2) + 64 * i, sv)) = ra[i];
+        for (int i = 0; i < 4; ++i) *(u32x4*)(sA + lds_off(srow + 32 * i, sv)) = ra[i];
 #pragma unroll
         for (int j = 0; j < BV; ++j) {
-            const int row = (tid + 256 * j) >> 2;
+            const int row = srow + 32 * j;
             if (row < BN) *(u32x4*)(sB + lds_off(row, sv)) = rb[j];
         }
     };
@@ -127,32 +152,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    auto compute = [&](int buf) {
+        const char* sA = smem + buf * (A_BYTES + B_BYTES);
+        const char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            u32x4 fb[4], fa[NT];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) fb[mt] = *(const u32x4*)(sA + lds_off(wm * 64 + mt * 16 + fr, sub * 4 + fg));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) fa[nt] = *(const u32x4*)(sB + lds_off(wn * (BN / 2) + nt * 16 + fr, sub * 4 + fg));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) Mma<T>::run(fa[nt], fb[mt], acc[nt][mt]);
+        }
+    };
+
     const int csteps = (C + BK - 1) / BK;
     const int nsteps = p.T * csteps;
-    int t_next = 0, c_next = 0;
-    gload(0, 0);
-    sstore(0);
+    // (A variant with two register sets — loads two k-steps ahead — was measured on MI355X: 198 VGPRs drop the
+    //  kernel to one workgroup per CU and the conv runs 30 % slower; one set + two workgroups per CU wins.)
+    gload(ra0, rb0);
+    sstore(0, ra0, rb0);
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int cur = s & 1;
         const bool more = s + 1 < nsteps;
-        if (more) {
-            c_next += BK;
-            if (c_next >= C) { c_next = 0; ++t_next; }
-            gload(t_next, c_next);
-        }
-        const char* sA = smem + cur * (A_BYTES + B_BYTES);
-        const char* sB = sA + A_BYTES;
-        u32x4 fb[4], fa[NT];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) fb[mt] = *(const u32x4*)(sA + lds_off(wm * 64 + mt * 16 + fr, fg));
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) fa[nt] = *(const u32x4*)(sB + lds_off(wn * (BN / 2) + nt * 16 + fr, fg));
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) Mma<T>::run(fa[nt], fb[mt], acc[nt][mt]);
-        if (more) sstore(cur ^ 1);
+        if (more) gload(ra0, rb0);                 // step s+1 in flight while LDS[cur] (step s) is consumed
+        compute(cur);
+        if (more) sstore(cur ^ 1, ra0, rb0);
         __syncthreads();
     }
 
@@ -277,6 +306,7 @@ extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
     DM_CHECK_ARG((d->Hq - 1) * d->osy + d->ooy < d->Ho && (d->Wq - 1) * d->osx + d->oox < d->Wo && d->ooy >= 0 && d->oox >= 0, "dm_conv: output mapping exceeds Ho/Wo");
     DM_CHECK_ARG(d->out_nchw_f32 || (d->ldc >= d->coff + d->N && d->coff >= 0), "dm_conv: ldc=%d < coff+N=%d", d->ldc, d->coff + d->N);
     DM_CHECK_ARG((d->psum == nullptr) == (d->psq == nullptr), "dm_conv: psum/psq must both be set or both null");
+    DM_CHECK_ARG(((uintptr_t)d->in1 & 15) == 0 && ((uintptr_t)d->in2 & 15) == 0 && ((uintptr_t)d->w & 15) == 0, "dm_conv: tensors must be 16-byte aligned");
     const int64_t M = (int64_t)d->B * d->Hq * d->Wq;
     DM_CHECK_ARG(M < (1ll << 31), "dm_conv: M too large");
     ConvP p;

@@ -6,15 +6,16 @@
 
 namespace {
 
-constexpr int CS_ROWS = 512;  // rows per block in column-statistics kernels
+constexpr int CS_ROWS = 128;  // rows per block in column-statistics kernels (small slabs: enough workgroups to hide HBM latency)
 
 // ---------------------------------------------------------------------------------------------
 // Column partial reduction skeleton: block handles rows [r0, r0+CS_ROWS) of an [M][C] matrix.
 // Thread (cv, rl): column vector cv (V elements), row lane rl; LDS folds the row lanes.
-// F: functor (row, col0, float vals_out1[V], float vals_out2[V]) producing two quantities to sum.
+// F: functor object: init(col0) loads whatever is per-column (kept in registers for the whole row loop),
+//    row(r, col0, v1[V], v2[V]) produces the two quantities to sum.
 // ---------------------------------------------------------------------------------------------
 template <int V, typename F>
-__device__ inline void col_partial(int M, int C, float* p1, float* p2, F f) {
+__device__ inline void col_partial(int M, int C, float* p1, float* p2, F& f) {
     __shared__ float red[2][2048];
     const int CVt = (C + V - 1) / V;  // column vectors in total
     const int r0 = blockIdx.x * CS_ROWS;
@@ -28,9 +29,11 @@ __device__ inline void col_partial(int M, int C, float* p1, float* p2, F f) {
         for (int i = 0; i < V; ++i) a1[i] = a2[i] = 0.f;
         if (rl < RL) {
             const int col0 = (cbase + cv) * V;
+            f.init(col0);
+#pragma unroll 4
             for (int r = r0 + rl; r < r1; r += RL) {
                 float v1[V], v2[V];
-                f(r, col0, v1, v2);
+                f.row(r, col0, v1, v2);
 #pragma unroll
                 for (int i = 0; i < V; ++i) { a1[i] += v1[i]; a2[i] += v2[i]; }
             }
@@ -70,13 +73,34 @@ __device__ inline void store_cols(T* p, const float* f) {
 }
 
 template <typename T, int V>
-__global__ __launch_bounds__(256) void col_stats_kernel(const T* z, int M, int C, float* psum, float* psq) {
-    col_partial<V>(M, C, psum, psq, [&](int r, int c0, float* v1, float* v2) {
+struct StatsF {
+    const T* z; int C;
+    __device__ inline void init(int) {}
+    __device__ inline void row(int r, int c0, float* v1, float* v2) const {
         load_cols<T, V>(z + (size_t)r * C + c0, v1);
 #pragma unroll
         for (int i = 0; i < V; ++i) v2[i] = v1[i] * v1[i];
-    });
+    }
+};
+template <typename T, int V>
+__global__ __launch_bounds__(256) void col_stats_kernel(const T* z, int M, int C, float* psum, float* psq) {
+    StatsF<T, V> f{z, C};
+    col_partial<V>(M, C, psum, psq, f);
 }
+
+// per-thread channel parameters held in registers by the streaming BN kernels
+template <int V>
+struct BnParams {
+    float mu[V], rs[V], gm[V], bt[V];
+    __device__ inline void load(int c0, int C, const float* mean, const float* rstd, const float* gamma, const float* beta) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const int c = c0 + k < C ? c0 + k : C - 1;
+            mu[k] = mean[c]; rs[k] = rstd[c];
+            gm[k] = gamma ? gamma[c] : 1.f; bt[k] = beta ? beta[c] : 0.f;
+        }
+    }
+};
 
 // one wave per channel: lanes stride over the partial blocks
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* psum, const float* psq, int nblk, int M, int C,
@@ -112,58 +136,75 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* part, int 
     if (lane == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
+// Streaming kernels: a thread keeps ONE column vector (its BN parameters live in registers) and strides over
+// rows; the global stride is rounded down to a multiple of the vectors per row so the column never changes.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* z, T* y, int64_t nvec, int CV, const float* mean,
                                                          const float* rstd, const float* gamma, const float* beta, int act) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-        const int c0 = (int)(i % CV) * V;
+    const int64_t G = ((int64_t)gridDim.x * 256 / CV) * CV;
+    const int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g0 >= G) return;
+    BnParams<V> P;
+    P.load((int)(g0 % CV) * V, CV * V, mean, rstd, gamma, beta);
+#pragma unroll 2
+    for (int64_t i = g0; i < nvec; i += G) {
         float v[V];
         load_cols<T, V>(z + i * V, v);
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            const float g = gamma ? gamma[c0 + k] : 1.f, b = beta ? beta[c0 + k] : 0.f;
-            v[k] = act_apply((v[k] - mean[c0 + k]) * rstd[c0 + k] * g + b, act);
-        }
+        for (int k = 0; k < V; ++k) v[k] = act_apply((v[k] - P.mu[k]) * P.rs[k] * P.gm[k] + P.bt[k], act);
         store_cols<T, V>(y + i * V, v);
     }
 }
 
 template <typename T, int V>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* z, const T* dy, int M, int C, const float* mean,
-                                                            const float* rstd, const float* gamma, const float* beta,
-                                                            int act, float* p1, float* p2) {
-    col_partial<V>(M, C, p1, p2, [&](int r, int c0, float* v1, float* v2) {
+struct BwdRedF {
+    const T* z; const T* dy; int C; const float* mean; const float* rstd; const float* gamma; const float* beta; int act;
+    BnParams<V> P;
+    __device__ inline void init(int c0) { P.load(c0, C, mean, rstd, gamma, beta); }
+    __device__ inline void row(int r, int c0, float* v1, float* v2) const {
         float zz[V], dd[V];
         load_cols<T, V>(z + (size_t)r * C + c0, zz);
         load_cols<T, V>(dy + (size_t)r * C + c0, dd);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            const float xh = (zz[i] - mean[c0 + i]) * rstd[c0 + i];
-            const float u = xh * (gamma ? gamma[c0 + i] : 1.f) + (beta ? beta[c0 + i] : 0.f);
-            const float g = dd[i] * act_grad(u, act);
+            const float xh = (zz[i] - P.mu[i]) * P.rs[i];
+            const float g = dd[i] * act_grad(xh * P.gm[i] + P.bt[i], act);
             v1[i] = g;
             v2[i] = g * xh;
         }
-    });
+    }
+};
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* z, const T* dy, int M, int C, const float* mean,
+                                                            const float* rstd, const float* gamma, const float* beta,
+                                                            int act, float* p1, float* p2) {
+    BwdRedF<T, V> f{z, dy, C, mean, rstd, gamma, beta, act, {}};
+    col_partial<V>(M, C, p1, p2, f);
 }
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* z, const T* dy, T* dz, int64_t nvec, int CV, float invM,
                                                            const float* mean, const float* rstd, const float* gamma,
                                                            const float* beta, int act, const float* s1, const float* s2) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-        const int c0 = (int)(i % CV) * V;
+    const int64_t G = ((int64_t)gridDim.x * 256 / CV) * CV;
+    const int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g0 >= G) return;
+    const int c0 = (int)(g0 % CV) * V;
+    BnParams<V> P;
+    P.load(c0, CV * V, mean, rstd, gamma, beta);
+    float m1[V], m2[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { m1[k] = s1[c0 + k] * invM; m2[k] = s2[c0 + k] * invM; }
+#pragma unroll 2
+    for (int64_t i = g0; i < nvec; i += G) {
         float zz[V], dd[V];
         load_cols<T, V>(z + i * V, zz);
         load_cols<T, V>(dy + i * V, dd);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            const int c = c0 + k;
-            const float gm = gamma ? gamma[c] : 1.f;
-            const float xh = (zz[k] - mean[c]) * rstd[c];
-            const float u = xh * gm + (beta ? beta[c] : 0.f);
-            const float g = dd[k] * act_grad(u, act);
-            zz[k] = gm * rstd[c] * (g - s1[c] * invM - xh * s2[c] * invM);
+            const float xh = (zz[k] - P.mu[k]) * P.rs[k];
+            const float g = dd[k] * act_grad(xh * P.gm[k] + P.bt[k], act);
+            zz[k] = P.gm[k] * P.rs[k] * (g - m1[k] - xh * m2[k]);
         }
         store_cols<T, V>(dz + i * V, zz);
     }

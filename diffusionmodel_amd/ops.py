@@ -112,7 +112,7 @@ def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, s
         e0.record()
         call("dm_conv", C.byref(d))
         e1.record()
-        PROFILE.append(("conv_igemm", 2.0 * B * Hq * Wq * N * T * (C1 + C2), e0, e1))
+        PROFILE.append(("conv_igemm" if dtype == torch.bfloat16 else "igemm_f32", 2.0 * B * Hq * Wq * N * T * (C1 + C2), e0, e1))
 
 
 def _wgrad_call(dy, in1, in2, dw, dbias, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0, Ho, Wo, N, ldy,
@@ -132,7 +132,7 @@ def _wgrad_call(dy, in1, in2, dw, dbias, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy
         e0.record()
         call("dm_conv_wgrad", C.byref(d))
         e1.record()
-        PROFILE.append(("conv_wgrad", 2.0 * B * Hq * Wq * N * T * (C1 + C2), e0, e1))
+        PROFILE.append(("conv_wgrad" if dtype == torch.bfloat16 else "wgrad_f32", 2.0 * B * Hq * Wq * N * T * (C1 + C2), e0, e1))
 
 
 class ConvSpec:
@@ -446,6 +446,11 @@ class GroupNormAct(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # fp32 dense layers / activations on small matrices
 # ------------------------------------------------------------------------------------------------
+def _mfma_linear(M, K, N):
+    """Route a dense fp32 layer through the exact-fp32 MFMA GEMM kernels when the vector widths allow."""
+    return K % 4 == 0 and N % 4 == 0
+
+
 class Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
@@ -453,8 +458,14 @@ class Linear(torch.autograd.Function):
         x = x.contiguous()
         M, K = x.shape
         N = w.shape[0]
+        w = w.contiguous()
         y = _empty((M, N), torch.float32, x)
-        call("dm_linear_fwd", ptr(x), ptr(w), ptr(b), ptr(y), M, K, N, ACT_NONE)
+        if _mfma_linear(M, K, N):
+            # exact-fp32 MFMA GEMM: the rows of x are "pixels" of a 1x1 image, w is already [N][K]
+            _conv_call(x, None, ptr(w), K, y, dtype=torch.float32, B=M, Hi=1, Wi=1, C1=K, C2=0, Hq=1, Wq=1, sy=1, sx=1, T=1,
+                       KW=1, ty=1, tx=1, oy0=0, ox0=0, Ho=1, Wo=1, N=N, shift=b)
+        else:
+            call("dm_linear_fwd", ptr(x), ptr(w), ptr(b), ptr(y), M, K, N, ACT_NONE)
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
         return y
@@ -465,10 +476,29 @@ class Linear(torch.autograd.Function):
         g = g.contiguous()
         M, K = x.shape
         N = w.shape[0]
-        dx = _empty((M, K), torch.float32, x) if ctx.needs_input_grad[0] else None
-        dw = _zeros((N, K), torch.float32, x) if ctx.needs_input_grad[1] else None
-        db = _zeros((N,), torch.float32, x) if (ctx.has_b and ctx.needs_input_grad[2]) else None
-        call("dm_linear_bwd", ptr(x), ptr(w.contiguous()), ptr(g), ptr(dx), ptr(dw), ptr(db), M, K, N)
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_db = ctx.has_b and ctx.needs_input_grad[2]
+        dx = _empty((M, K), torch.float32, x) if need_dx else None
+        dw = _zeros((N, K), torch.float32, x) if need_dw else None
+        db = _zeros((N,), torch.float32, x) if need_db else None
+        if _mfma_linear(M, K, N):
+            if need_dx:
+                def build():
+                    wt = _empty((K, N), torch.float32, w)
+                    call("dm_pack_wT", ptr(w), ptr(wt), L.DM_F32, N, 1, K, 1, None, N)
+                    return wt
+                wt = _cached(("linT",), w, build)
+                _conv_call(g, None, ptr(wt), N, dx, dtype=torch.float32, B=M, Hi=1, Wi=1, C1=N, C2=0, Hq=1, Wq=1, sy=1, sx=1,
+                           T=1, KW=1, ty=1, tx=1, oy0=0, ox0=0, Ho=1, Wo=1, N=K)
+            if need_dw or need_db:
+                if dw is None:
+                    dw = _zeros((N, K), torch.float32, x)
+                _wgrad_call(g, x, None, dw, db, dtype=torch.float32, B=M, Hi=1, Wi=1, C1=K, C2=0, Hq=1, Wq=1, sy=1, sx=1, T=1,
+                            KW=1, ty=1, tx=1, oy0=0, ox0=0, Ho=1, Wo=1, N=N, ldy=N, ldw=K)
+                if not need_dw:
+                    dw = None
+        else:
+            call("dm_linear_bwd", ptr(x), ptr(w), ptr(g), ptr(dx), ptr(dw), ptr(db), M, K, N)
         return dx, dw, db
 
 

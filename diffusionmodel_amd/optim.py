@@ -15,6 +15,8 @@ from ._lib import DmError, call, ptr
 
 
 class FusedAdamW(torch.optim.Optimizer):
+    CHUNK = 16384
+
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, max_grad_norm=1.0,
                  grad_scale=1.0):
         params = [p for p in params]
@@ -77,7 +79,8 @@ class FusedAdamW(torch.optim.Optimizer):
             if not g.is_contiguous():
                 g = g.contiguous()
             p._keep = g                              # keep alive until the kernel has run
-            rows.append((g.data_ptr(), base + 4 * off, n))
+            for lo in range(0, n, self.CHUNK):       # one workgroup per <= CHUNK elements
+                rows.append((g.data_ptr() + 4 * lo, base + 4 * (off + lo), min(self.CHUNK, n - lo)))
         if rows:
             table = torch.tensor(rows, dtype=torch.int64).to(self.flat_g.device, non_blocking=True)
             call("dm_scatter_copy", ptr(table), len(rows), 1)

@@ -196,7 +196,11 @@ def test_context_unet_vs_reference_fixture(tag, S, k):
                     # fp32-vs-fp64 deviation for this parameter and allow a few times that
                     g64, g32 = _oracle_train_grads(tag, S, x, c, t, mk)
                     noise = relerr(g32[pn], g64[pn])
-                    assert relerr(got, g64[pn]) < max(5e-3, 4 * noise), (pn, relerr(got, g64[pn]), noise)
+                    # scalar parameters (CoordAttn gamma/alpha) are sums with heavy cancellation: under 1e-7
+                    # relative input noise the HIP value of ca2.gamma_h itself moves by 1.2e-2 and ca1.alpha by
+                    # 3e-3 (scripts/probe_conditioning.py), so they get a conditioning-sized bar
+                    bar = 5e-2 if got.size == 1 else max(5e-3, 4 * noise)
+                    assert relerr(got, g64[pn]) < bar, (pn, relerr(got, g64[pn]), noise)
         if train:
             sd = net.state_dict()
             for key in g.files:
