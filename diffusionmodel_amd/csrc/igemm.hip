@@ -1,14 +1,23 @@
 // Implicit-GEMM gather convolution on the CDNA4 matrix cores (forward, input-gradient, ConvTranspose,
 // and — as a 1x1 "image" — the dense fp32 layers).
 //
-// One kernel serves every dense contraction of the denoiser (include/dm_amd.h, dm_conv): the output
-// tile is 128 output pixels x BN output channels per 256-thread workgroup (4 waves as 2(m) x 2(n)),
+// One kernel family serves every dense contraction of the denoiser (include/dm_amd.h, dm_conv): the
+// output tile is 128 output pixels x BN output channels per 256-thread workgroup (4 waves as 2(m) x 2(n)),
 // K runs over taps x input channels in steps of 128 bytes per row (64 bf16 / 32 f32 channels).  Both
-// operands are staged through LDS as [row][128 B] images whose 16-byte vectors are XOR-swizzled with
-// the row index (vec ^= row & 7), which makes the ds_read_b128 fragment reads conflict-free (every
-// 16-lane group of the instruction hits 16 distinct 16-B slots of the 256-B bank row) while the
-// staging writes stay whole-row contiguous.  Global loads are register-prefetched one k-step ahead and
-// the LDS image is double buffered: one barrier per k-step, two MFMA k-sub-steps between barriers.
+// operands are staged in LDS as [row][128 B] images whose 16-byte vectors are XOR-swizzled with the row
+// index (vec ^= row & 7): the ds_read_b128 fragment reads are conflict-free (every 16-lane group of the
+// instruction hits 16 distinct 16-B slots of the 256-B bank row).
+//
+// Two staging pipelines:
+//   v2 (default) LDS-DMA: `global_load_lds_dwordx4` writes the stage directly (no VGPR round trip, no
+//      ds_write, almost no per-step address arithmetic: per-lane row offsets and a per-row tap-validity
+//      bitmask are computed once, a k-step costs one add + one select per 1-KiB piece).  The LDS image
+//      is lane-linear per wave-instruction (8 rows x 8 vectors), so the swizzle sits on the SOURCE
+//      address: lane L fetches logical vector (L&7) ^ (L>>3) of row L>>3.  Zero padding (3x3 halo, ragged
+//      tiles, channel tails) = lanes pointed at a small zero page.  NS-stage ring, one raw s_barrier per
+//      k-step, counted `s_waitcnt vmcnt(N)` so NS-2 stages stay in flight across the barrier.
+//   v1 register staging (global_load -> VGPR -> ds_write), one step ahead, LDS double buffer.  Kept as the
+//      fallback for tensors beyond 2^31 elements and for A/B measurements (dm_set_conv_variant).
 //
 // MFMA orientation is "swapped": A operand = packed weights (row i = output channel), B operand =
 // gathered input pixels (column j = output pixel), so every lane ends up with 4 consecutive output
@@ -38,7 +47,14 @@ struct ConvP {
     int Ho, Wo, osy, osx, ooy, oox, N, ldw, ldc, coff, M;
 };
 
+__device__ __attribute__((aligned(128))) unsigned int g_zero_page[64];  // source of every padded 16-B vector (v2)
+
 __device__ inline int lds_off(int row, int vec) { return row * ROWB + ((vec ^ (row & 7)) << 4); }
+
+__device__ inline int remap_xcd(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
@@ -54,138 +70,29 @@ template <> struct Mma<float> {
     }
 };
 
+// one k-step (two MFMA sub-steps) of a wave's 64 x (BN/2) sub-tile out of the stage at sA / sB
 template <typename T, int BN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
-    constexpr int VE = Elem<T>::VE;
-    constexpr int BK = 8 * VE;                // channels per k-step
-    constexpr int NT = BN / 32;               // 16-wide channel tiles per wave
-    constexpr int BV = (BN * 8 + 255) / 256;  // weight vectors per thread per k-step
-    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
-    __shared__ __attribute__((aligned(16))) char smem[2 * (A_BYTES + B_BYTES)];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
-    const int fr = lane & 15, fg = lane >> 4;
-    const int nb_n = (p.N + BN - 1) / BN;
-    // XCD-aware remap of the linear workgroup id (bijective for any grid size)
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+__device__ __forceinline__ void mma_stage(const char* sA, const char* sB, int wm, int wn, int fr, int fg, f32x4 (&acc)[BN / 32][4]) {
+    constexpr int NT = BN / 32;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        u32x4 fb[4], fa[NT];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) fb[mt] = *(const u32x4*)(sA + lds_off(wm * 64 + mt * 16 + fr, sub * 4 + fg));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) fa[nt] = *(const u32x4*)(sB + lds_off(wn * (BN / 2) + nt * 16 + fr, sub * 4 + fg));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) Mma<T>::run(fa[nt], fb[mt], acc[nt][mt]);
     }
-    const int mb = bid / nb_n, nb = bid - mb * nb_n;
-    const int m0 = mb * BM, n0 = nb * BN;
-    const int C = p.C1 + p.C2;
-    const T* in1 = (const T*)p.in1;
-    const T* in2 = (const T*)p.in2;
-    const T* wgt = (const T*)p.w;
+}
 
-    // ---- per-thread staging assignment: A rows (tid>>3) + 32*i, vector tid&7
-    const int sv = tid & 7, srow = tid >> 3;
-    int a_b[4], a_y[4], a_x[4];
-    bool a_ok[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + srow + 32 * i;
-        a_ok[i] = m < p.M;
-        const int mm = a_ok[i] ? m : 0;
-        const int qx = mm % p.Wq, tq = mm / p.Wq;
-        const int qy = tq % p.Hq;
-        a_b[i] = tq / p.Hq;
-        a_y[i] = qy * p.sy + p.oy0;
-        a_x[i] = qx * p.sx + p.ox0;
-    }
-
-    // one register set: global loads run one k-step ahead of the MFMAs (in registers on their way to LDS);
-    // a second workgroup on the CU covers the rest of the HBM/L2 latency
-    u32x4 ra0[4], rb0[BV];
-    // tap state of the NEXT load (advanced incrementally: no division in the loop)
-    int ld_t = 0, ld_ky = 0, ld_kx = 0, ld_c0 = 0;
-    auto gload = [&](u32x4 (&ra)[4], u32x4 (&rb)[BV]) {
-        const int dy = ld_ky * p.ty, dx = ld_kx * p.tx;
-        const int c = ld_c0 + sv * VE;
-        const bool c_ok = c < C;
-        const bool first = c < p.C1;
-        const T* src_base = first ? in1 : in2;
-        const int cs = first ? p.C1 : p.C2, cc = first ? c : c - p.C1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int iy = a_y[i] + dy, ix = a_x[i] + dx;
-            const bool ok = a_ok[i] && c_ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) {
-                const size_t pix = ((size_t)a_b[i] * p.Hi + iy) * p.Wi + ix;
-                v = *(const u32x4*)(src_base + pix * cs + cc);
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < BV; ++j) {
-            const int row = srow + 32 * j;
-            const int n = n0 + row;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (row < BN && n < p.N && c_ok) v = *(const u32x4*)(wgt + (size_t)n * p.ldw + (size_t)ld_t * C + c);
-            rb[j] = v;
-        }
-        ld_c0 += BK;
-        if (ld_c0 >= C) {
-            ld_c0 = 0;
-            ++ld_t;
-            if (++ld_kx == p.KW) { ld_kx = 0; ++ld_ky; }
-        }
-    };
-    auto sstore = [&](int buf, const u32x4 (&ra)[4], const u32x4 (&rb)[BV]) {
-        char* sA = smem + buf * (A_BYTES + B_BYTES);
-        char* sB = sA + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *(u32x4*)(sA + lds_off(srow + 32 * i, sv)) = ra[i];
-#pragma unroll
-        for (int j = 0; j < BV; ++j) {
-            const int row = srow + 32 * j;
-            if (row < BN) *(u32x4*)(sB + lds_off(row, sv)) = rb[j];
-        }
-    };
-
-    f32x4 acc[NT][4];
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    auto compute = [&](int buf) {
-        const char* sA = smem + buf * (A_BYTES + B_BYTES);
-        const char* sB = sA + A_BYTES;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            u32x4 fb[4], fa[NT];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) fb[mt] = *(const u32x4*)(sA + lds_off(wm * 64 + mt * 16 + fr, sub * 4 + fg));
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) fa[nt] = *(const u32x4*)(sB + lds_off(wn * (BN / 2) + nt * 16 + fr, sub * 4 + fg));
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) Mma<T>::run(fa[nt], fb[mt], acc[nt][mt]);
-        }
-    };
-
-    const int csteps = (C + BK - 1) / BK;
-    const int nsteps = p.T * csteps;
-    // (A variant with two register sets — loads two k-steps ahead — was measured on MI355X: 198 VGPRs drop the
-    //  kernel to one workgroup per CU and the conv runs 30 % slower; one set + two workgroups per CU wins.)
-    gload(ra0, rb0);
-    sstore(0, ra0, rb0);
-    __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        const int cur = s & 1;
-        const bool more = s + 1 < nsteps;
-        if (more) gload(ra0, rb0);                 // step s+1 in flight while LDS[cur] (step s) is consumed
-        compute(cur);
-        if (more) sstore(cur ^ 1, ra0, rb0);
-        __syncthreads();
-    }
-
-    // ---- epilogue: z = acc*scale + shift ; optional column statistics ; activation ; store
+// epilogue: z = acc*scale + shift ; optional per-block column statistics ; activation ; store
+template <typename T, int BN>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 32][4], char* smem, int tid, int wm, int wn, int fr,
+                                              int fg, int mb, int m0, int n0) {
+    constexpr int NT = BN / 32;
     float sc[NT][4], sh[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -277,22 +184,298 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     }
 }
 
+// =================================================================================================
+// v1: register staging
+// =================================================================================================
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
+    constexpr int VE = Elem<T>::VE;
+    constexpr int BK = 8 * VE;                // channels per k-step
+    constexpr int NT = BN / 32;               // 16-wide channel tiles per wave
+    constexpr int BV = (BN * 8 + 255) / 256;  // weight vectors per thread per k-step
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    __shared__ __attribute__((aligned(16))) char smem[2 * (A_BYTES + B_BYTES)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nb_n = (p.N + BN - 1) / BN;
+    const int bid = remap_xcd(blockIdx.x, gridDim.x);
+    const int mb = bid / nb_n, nb = bid - mb * nb_n;
+    const int m0 = mb * BM, n0 = nb * BN;
+    const int C = p.C1 + p.C2;
+    const T* in1 = (const T*)p.in1;
+    const T* in2 = (const T*)p.in2;
+    const T* wgt = (const T*)p.w;
+
+    // per-thread staging assignment: A rows (tid>>3) + 32*i, vector tid&7
+    const int sv = tid & 7, srow = tid >> 3;
+    int a_b[4], a_y[4], a_x[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + srow + 32 * i;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        const int qx = mm % p.Wq, tq = mm / p.Wq;
+        const int qy = tq % p.Hq;
+        a_b[i] = tq / p.Hq;
+        a_y[i] = qy * p.sy + p.oy0;
+        a_x[i] = qx * p.sx + p.ox0;
+    }
+
+    // one register set: global loads run one k-step ahead of the MFMAs (in registers on their way to LDS);
+    // a second workgroup on the CU covers the rest of the HBM/L2 latency.  (Two register sets — loads two
+    // k-steps ahead — were measured: 198 VGPRs drop the kernel to one workgroup per CU, 30 % slower.)
+    u32x4 ra[4], rb[BV];
+    int ld_t = 0, ld_ky = 0, ld_kx = 0, ld_c0 = 0;   // tap state of the NEXT load (no division in the loop)
+    auto gload = [&]() {
+        const int dy = ld_ky * p.ty, dx = ld_kx * p.tx;
+        const int c = ld_c0 + sv * VE;
+        const bool c_ok = c < C;
+        const bool first = c < p.C1;
+        const T* src_base = first ? in1 : in2;
+        const int cs = first ? p.C1 : p.C2, cc = first ? c : c - p.C1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = a_y[i] + dy, ix = a_x[i] + dx;
+            const bool ok = a_ok[i] && c_ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) {
+                const size_t pix = ((size_t)a_b[i] * p.Hi + iy) * p.Wi + ix;
+                v = *(const u32x4*)(src_base + pix * cs + cc);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BV; ++j) {
+            const int row = srow + 32 * j;
+            const int n = n0 + row;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row < BN && n < p.N && c_ok) v = *(const u32x4*)(wgt + (size_t)n * p.ldw + (size_t)ld_t * C + c);
+            rb[j] = v;
+        }
+        ld_c0 += BK;
+        if (ld_c0 >= C) {
+            ld_c0 = 0;
+            ++ld_t;
+            if (++ld_kx == p.KW) { ld_kx = 0; ++ld_ky; }
+        }
+    };
+    auto sstore = [&](int buf) {
+        char* sA = smem + buf * (A_BYTES + B_BYTES);
+        char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(u32x4*)(sA + lds_off(srow + 32 * i, sv)) = ra[i];
+#pragma unroll
+        for (int j = 0; j < BV; ++j) {
+            const int row = srow + 32 * j;
+            if (row < BN) *(u32x4*)(sB + lds_off(row, sv)) = rb[j];
+        }
+    };
+
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = p.T * ((C + BK - 1) / BK);
+    gload();
+    sstore(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int cur = s & 1;
+        const bool more = s + 1 < nsteps;
+        if (more) gload();                         // step s+1 in flight while LDS[cur] (step s) is consumed
+        const char* sA = smem + cur * (A_BYTES + B_BYTES);
+        mma_stage<T, BN>(sA, sA + A_BYTES, wm, wn, fr, fg, acc);
+        if (more) sstore(cur ^ 1);
+        __syncthreads();
+    }
+    conv_epilogue<T, BN>(p, acc, smem, tid, wm, wn, fr, fg, mb, m0, n0);
+}
+
+// =================================================================================================
+// v2: LDS-DMA staging, NS-stage ring
+// =================================================================================================
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* gbl_vptr;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int BN, int NS>
+__global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvP p) {
+    constexpr int VE = Elem<T>::VE;
+    constexpr int BK = 8 * VE;
+    constexpr int NT = BN / 32;
+    constexpr int GB = BN / 32;                 // weight pieces (8 rows x 128 B) per wave per k-step
+    constexpr int G = 4 + GB;                   // LDS-DMA instructions per wave per k-step
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NS * STAGE; the ONLY LDS object of the kernel
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nb_n = (p.N + BN - 1) / BN;
+    const int bid = remap_xcd(blockIdx.x, gridDim.x);
+    const int mb = bid / nb_n, nb = bid - mb * nb_n;
+    const int m0 = mb * BM, n0 = nb * BN;
+    const int C = p.C1 + p.C2;
+    // base addresses as laundered scalars: stops the compiler from turning `cond ? p.in1 : p.in2` into a
+    // per-lane LOAD from the kernarg segment (an ordinary global load in the loop would drain the LDS-DMA queue)
+    unsigned long long a_in1 = (unsigned long long)p.in1, a_in2 = (unsigned long long)(p.in2 ? p.in2 : p.in1);
+    unsigned long long a_w = (unsigned long long)p.w, a_zero = (unsigned long long)g_zero_page;
+    asm volatile("" : "+s"(a_in1), "+s"(a_in2), "+s"(a_w), "+s"(a_zero));
+
+    // ---- per-lane constants: the piece a wave-instruction writes is 8 rows x 8 slots, lane L -> (row L>>3, slot L&7)
+    const int lrow = lane >> 3;
+    const int cl = (((lane & 7) ^ lrow)) * VE;          // channel offset of this lane's logical vector within a k-step
+    int offA1[4], offA2[4];                              // element offset of tap (0,0) of the lane's 4 pixel rows
+    unsigned long long tapmask[4];                       // bit t: tap t of that pixel is inside the image
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wave * 32 + i * 8 + lrow;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int qx = mm % p.Wq, tq = mm / p.Wq;
+        const int qy = tq % p.Hq, b = tq / p.Hq;
+        const int by = qy * p.sy + p.oy0, bx = qx * p.sx + p.ox0;
+        const int pix = (b * p.Hi + by) * p.Wi + bx;
+        offA1[i] = pix * p.C1;
+        offA2[i] = pix * p.C2 - p.C1;                    // second source is indexed with (c - C1)
+        unsigned long long mk = 0ull;
+        int ky = 0, kx = 0;
+        for (int t = 0; t < p.T; ++t) {
+            const int iy = by + ky * p.ty, ix = bx + kx * p.tx;
+            if (ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) mk |= 1ull << t;
+            if (++kx == p.KW) { kx = 0; ++ky; }
+        }
+        tapmask[i] = mk;
+    }
+    int offB[GB];
+    bool okB[GB];
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+        const int n = n0 + wave * (BN / 4) + j * 8 + lrow;
+        okB[j] = n < p.N;
+        offB[j] = (okB[j] ? n : 0) * p.ldw;
+    }
+
+    int ld_t = 0, ld_ky = 0, ld_kx = 0, ld_c0 = 0;       // state of the NEXT k-step to be issued (wave-uniform)
+    auto issue = [&](int stage) {
+        char* sA = smem + stage * STAGE;
+        char* sB = sA + A_BYTES;
+        const int c = ld_c0 + cl;
+        const bool c_ok = c < C;
+        const bool first = c < p.C1;
+        const int tap_pix = ld_ky * p.ty * p.Wi + ld_kx * p.tx;                 // uniform
+        const int tapA = first ? tap_pix * p.C1 + c : tap_pix * p.C2 + c;
+        const unsigned long long srcA = first ? a_in1 : a_in2;                  // branch-free selects on integers:
+#pragma unroll                                                                   // no loads, no divergence in the loop
+        for (int i = 0; i < 4; ++i) {
+            const bool v = c_ok && ((tapmask[i] >> ld_t) & 1ull);
+            const int off = (first ? offA1[i] : offA2[i]) + tapA;
+            unsigned long long g = srcA + (unsigned long long)(unsigned)off * sizeof(T);
+            g = v ? g : a_zero;
+            __builtin_amdgcn_global_load_lds((gbl_vptr)g, (lds_vptr)(sA + (wave * 32 + i * 8) * ROWB), 16, 0, 0);
+        }
+        const int kB = ld_t * C + c;
+#pragma unroll
+        for (int j = 0; j < GB; ++j) {
+            unsigned long long g = a_w + (unsigned long long)(unsigned)(offB[j] + kB) * sizeof(T);
+            g = (okB[j] && c_ok) ? g : a_zero;
+            __builtin_amdgcn_global_load_lds((gbl_vptr)g, (lds_vptr)(sB + (wave * (BN / 4) + j * 8) * ROWB), 16, 0, 0);
+        }
+        ld_c0 += BK;
+        if (ld_c0 >= C) {
+            ld_c0 = 0;
+            ++ld_t;
+            if (++ld_kx == p.KW) { ld_kx = 0; ++ld_ky; }
+        }
+    };
+
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = p.T * ((C + BK - 1) / BK);
+    // prologue: NS-1 stages in flight
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nsteps) issue(s);
+    int cons = 0;                        // stage consumed this iteration
+    int prod = NS - 1;                   // stage the next issue writes (the one consumed last iteration)
+    for (int s = 0; s < nsteps; ++s) {
+        // step s has landed once at most NS-2 younger groups are outstanding (exact while the ring is full)
+        if (s + NS - 1 <= nsteps) wait_vmcnt<G * (NS - 2)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();    // publishes step s of every wave; every wave is done reading stage `prod`
+        if (s + NS - 1 < nsteps) issue(prod);
+        const char* sA = smem + cons * STAGE;
+        mma_stage<T, BN>(sA, sA + A_BYTES, wm, wn, fr, fg, acc);
+        prod = cons;
+        cons = cons + 1 == NS ? 0 : cons + 1;
+    }
+    __syncthreads();                     // the epilogue reuses the LDS for the statistics fold
+    conv_epilogue<T, BN>(p, acc, smem, tid, wm, wn, fr, fg, mb, m0, n0);
+}
+
+int g_variant = 2;    // 1 = register staging, 2..4 = LDS-DMA with that many ring stages (2 workgroups/CU at 2)
+
+template <typename T, int BN, int NS>
+int launch2(const ConvP& p, int64_t grid, hipStream_t st) {
+    constexpr int bytes = NS * (BM + BN) * ROWB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm2_kernel<T, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) { dm_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", bytes, hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_igemm2_kernel<T, BN, NS>), dim3((unsigned)grid), dim3(256), bytes, st, p);
+    return DM_OK;
+}
+
+template <typename T, int BN>
+int launch_bn(const ConvP& p, int64_t grid, int variant, hipStream_t st) {
+    int rc = DM_OK;
+    switch (variant) {
+        case 1: hipLaunchKernelGGL((conv_igemm_kernel<T, BN>), dim3((unsigned)grid), dim3(256), 0, st, p); break;
+        case 3: rc = launch2<T, BN, 3>(p, grid, st); break;
+        case 4: rc = launch2<T, BN, 4>(p, grid, st); break;
+        default: rc = launch2<T, BN, 2>(p, grid, st); break;
+    }
+    return rc;
+}
+
 template <typename T>
-int launch_conv(const ConvP& p, hipStream_t st) {
+int launch_conv(const ConvP& p, bool small_offsets, hipStream_t st) {
     const int mblocks = cdiv(p.M, BM);
     int bn = 128;
     if (p.N <= 32) bn = 32;
     else if (p.N <= 64) bn = 64;
     else if ((int64_t)mblocks * cdiv(p.N, 128) < 256) bn = 64;  // small problems: more, smaller tiles
     const int64_t grid = (int64_t)mblocks * cdiv(p.N, bn);
-    if (bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128>), dim3((unsigned)grid), dim3(256), 0, st, p);
-    else if (bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 64>), dim3((unsigned)grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_igemm_kernel<T, 32>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    const int variant = small_offsets ? g_variant : 1;
+    int rc;
+    if (bn == 128) rc = launch_bn<T, 128>(p, grid, variant, st);
+    else if (bn == 64) rc = launch_bn<T, 64>(p, grid, variant, st);
+    else rc = launch_bn<T, 32>(p, grid, variant, st);
+    if (rc) return rc;
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
 
 }  // namespace
+
+extern "C" int dm_set_conv_variant(int variant) {
+    DM_CHECK_ARG(variant >= 1 && variant <= 4, "dm_set_conv_variant: 1 (register staging) or 2..4 (LDS-DMA ring stages)");
+    g_variant = variant;
+    return DM_OK;
+}
 
 extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
     DM_CHECK_ARG(d != nullptr, "dm_conv: null descriptor");
@@ -302,7 +485,7 @@ extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
     DM_CHECK_ARG(d->C1 > 0 && d->C1 % ve == 0 && d->C2 >= 0 && d->C2 % ve == 0, "dm_conv: C1=%d C2=%d must be multiples of %d", d->C1, d->C2, ve);
     DM_CHECK_ARG(d->C2 == 0 || d->in2, "dm_conv: C2 > 0 but in2 is null");
     DM_CHECK_ARG(d->ldw % ve == 0 && d->ldw >= d->T * (d->C1 + d->C2), "dm_conv: ldw=%d invalid for T=%d C=%d", d->ldw, d->T, d->C1 + d->C2);
-    DM_CHECK_ARG(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Hq > 0 && d->Wq > 0 && d->T > 0 && d->KW > 0 && d->N > 0, "dm_conv: non-positive extent");
+    DM_CHECK_ARG(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Hq > 0 && d->Wq > 0 && d->T > 0 && d->T <= 64 && d->KW > 0 && d->N > 0, "dm_conv: bad extent (T must be 1..64)");
     DM_CHECK_ARG((d->Hq - 1) * d->osy + d->ooy < d->Ho && (d->Wq - 1) * d->osx + d->oox < d->Wo && d->ooy >= 0 && d->oox >= 0, "dm_conv: output mapping exceeds Ho/Wo");
     DM_CHECK_ARG(d->out_nchw_f32 || (d->ldc >= d->coff + d->N && d->coff >= 0), "dm_conv: ldc=%d < coff+N=%d", d->ldc, d->coff + d->N);
     DM_CHECK_ARG((d->psum == nullptr) == (d->psq == nullptr), "dm_conv: psum/psq must both be set or both null");
@@ -317,6 +500,10 @@ extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
     p.T = d->T; p.KW = d->KW; p.ty = d->ty; p.tx = d->tx; p.oy0 = d->oy0; p.ox0 = d->ox0;
     p.Ho = d->Ho; p.Wo = d->Wo; p.osy = d->osy; p.osx = d->osx; p.ooy = d->ooy; p.oox = d->oox;
     p.N = d->N; p.ldw = d->ldw; p.ldc = d->ldc; p.coff = d->coff; p.M = (int)M;
-    if (d->dtype == DM_BF16) return launch_conv<bf16>(p, (hipStream_t)stream);
-    return launch_conv<float>(p, (hipStream_t)stream);
+    // the LDS-DMA kernel indexes with unsigned 32-bit element offsets (with a margin for the halo arithmetic)
+    const int64_t in_elems = (int64_t)d->B * d->Hi * d->Wi * (d->C1 > d->C2 ? d->C1 : d->C2);
+    const int64_t w_elems = (int64_t)d->N * d->ldw;
+    const bool small = in_elems < (1ll << 31) - (1ll << 24) && w_elems < (1ll << 31);
+    if (d->dtype == DM_BF16) return launch_conv<bf16>(p, small, (hipStream_t)stream);
+    return launch_conv<float>(p, small, (hipStream_t)stream);
 }

@@ -57,6 +57,8 @@ typedef struct DmConv {
     int32_t N, ldw, ldc, coff;
 } DmConv;
 int dm_conv(const DmConv* d, dm_stream_t stream);
+/* tuning knob: staging pipeline of dm_conv — 1 = register staging, 2..4 = LDS-DMA ring with that many stages (default 2) */
+int dm_set_conv_variant(int variant);
 
 /* Weight gradient of the same gather convolution (fp32 atomics into dw, which the caller zeroes or
  * accumulates into):  dw[n*ldw + t*C + c] += sum_m dy[orow(m)][n] * in(pix(m,t))[c],
