@@ -86,7 +86,7 @@ _PROTOS = {
     "dm_sumsq": [vp, i64, vp],
     "dm_adamw": [vp, vp, vp, vp, i64, vp, vp],
 }
-_NO_STREAM = {"dm_set_conv_variant": ([i32], i32), "dm_version": ([], i32), "dm_last_error": ([], C.c_char_p), "dm_colstat_blocks": ([i32], i32)}
+_NO_STREAM = {"dm_set_conv_variant": ([i32], i32), "dm_set_wgrad_variant": ([i32], i32), "dm_version": ([], i32), "dm_last_error": ([], C.c_char_p), "dm_colstat_blocks": ([i32], i32)}
 
 EXPORTED = sorted(list(_PROTOS) + list(_NO_STREAM))
 
@@ -115,6 +115,9 @@ def load():
         fn.argtypes = list(args)
         fn.restype = res
     _lib = lib
+    v = os.environ.get("DM_WGRAD_VARIANT")
+    if v and lib.dm_set_wgrad_variant(int(v)) != 0:
+        raise DmError(lib.dm_last_error().decode())
     v = os.environ.get("DM_CONV_VARIANT")      # tuning knob, see dm_set_conv_variant in dm_amd.h
     if v:
         if lib.dm_set_conv_variant(int(v)) != 0:

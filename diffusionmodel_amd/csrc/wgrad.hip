@@ -175,29 +175,232 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     if (do_bias && n0 + tid < p.N) atomicAdd(p.dbias + n0 + tid, bias_acc);
 }
 
+// =================================================================================================
+// v2: LDS-DMA staging.  Stage = [KD pixels][128 channels] images of dy and of the tap-shifted input,
+// rows unpadded (so a 1-KiB DMA piece = 4 (bf16) / 2 (f32) whole rows) and XOR-swizzled in chunks of
+// 32 B (bf16) / 64 B (f32): chunk ^= row & 7 — the 8 pixel rows a 32-lane half reads in one transposed
+// read then sit in 8 disjoint bank groups.  As in the forward kernel the swizzle is applied on the DMA
+// SOURCE side (lane -> logical vector) and padding comes from a zero page.  KD = 64 (bf16) / 32 (f32)
+// pixels per barrier, 2-stage ring, 2 workgroups per CU.  Requires the identity output mapping
+// (dy row of pixel m is row m), which is every call the model makes.
+// =================================================================================================
+__device__ __attribute__((aligned(128))) unsigned int g_wg_zero_page[64];
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* gbl_vptr;
+
+template <typename T> struct Wg2Cfg;
+template <> struct Wg2Cfg<bf16> { static constexpr int KD = 64, RB = 256, SPC = 2, RPP = 4; };   // rows per piece
+template <> struct Wg2Cfg<float> { static constexpr int KD = 32, RB = 512, SPC = 4, RPP = 2; };
+
 template <typename T>
-int launch_wgrad(WgP& p, int splitk_req, hipStream_t st) {
-    constexpr int KD = WgCfg<T>::KD;
+__device__ __forceinline__ int wg2_off(int row, int elem) {   // byte offset of element `elem` (0..127) of pixel row `row`
+    constexpr int RB = Wg2Cfg<T>::RB, CH = Wg2Cfg<T>::SPC * 16, EPC = CH / (int)sizeof(T);   // elements per swizzle chunk
+    return row * RB + (((elem / EPC) ^ (row & 7)) * CH) + (elem % EPC) * (int)sizeof(T);
+}
+
+__device__ __forceinline__ bf16x8 tr_frag2(const char* tile, int row0, int col_base, int lane) {
+    // 16x16x32 operand fragment: lane group g holds pixels row0 + {4g..4g+3} and row0 + 16 + {4g..4g+3}
+    const int g = lane >> 4, il = lane & 15, q = il >> 2, pp = il & 3;
+    const int r0 = row0 + 4 * g + q, r1 = r0 + 16;
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tile + wg2_off<bf16>(r0, col_base) + 8 * pp));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tile + wg2_off<bf16>(r1, col_base) + 8 * pp));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgP p) {
+    constexpr int VE = Elem<T>::VE;
+    constexpr int KD = Wg2Cfg<T>::KD, RB = Wg2Cfg<T>::RB, SPC = Wg2Cfg<T>::SPC, RPP = Wg2Cfg<T>::RPP;
+    constexpr int TILE = KD * RB, STAGE = 2 * TILE;          // 16 KiB per operand tile, 32 KiB per stage
+    constexpr int SLOTS = RB / 16;                            // 16-B slots per row
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * STAGE, the only LDS object
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wc = wave >> 1;
+    const int C = p.C1 + p.C2;
+    const int n0 = blockIdx.x * 128;
+    const int t = blockIdx.y / p.csteps_c, c0 = (blockIdx.y - t * p.csteps_c) * 128;
+    const int ky = t / p.KW, kx = t - ky * p.KW;
+    const int dyo = ky * p.ty + p.oy0, dxo = kx * p.tx + p.ox0;
+    unsigned long long a_dy = (unsigned long long)p.dy, a_in1 = (unsigned long long)p.in1;
+    unsigned long long a_in2 = (unsigned long long)(p.in2 ? p.in2 : p.in1), a_zero = (unsigned long long)g_wg_zero_page;
+    asm volatile("" : "+s"(a_dy), "+s"(a_in1), "+s"(a_in2), "+s"(a_zero));
+
+    const int step_lo = blockIdx.z * p.steps_per_split;
+    const int step_hi = min(step_lo + p.steps_per_split, p.total_steps);
+
+    // ---- per-lane DMA geometry: a piece = RPP rows; lane -> (row in piece, physical slot) -> logical vector
+    const int lr = lane / SLOTS, ps = lane % SLOTS;
+    int prow[4];                 // the lane's pixel row (within the stage) for each of the wave's 4 pieces per tile
+    int lvec[4];                 // logical 16-B vector index it must fetch for that row (swizzle on the source side)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        prow[j] = (wave * 4 + j) * RPP + lr;
+        lvec[j] = (((ps / SPC) ^ (prow[j] & 7)) * SPC) | (ps % SPC);
+    }
+    // tracked pixel coordinates of the 4 rows (advanced by KD pixels per step without divisions)
+    int tb[4], tyq[4], txq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = step_lo * KD + prow[j];
+        txq[j] = m % p.Wq;
+        const int tq = m / p.Wq;
+        tyq[j] = tq % p.Hq;
+        tb[j] = tq / p.Hq;
+    }
+    const int dqx = KD % p.Wq, dq1 = KD / p.Wq, dqy = dq1 % p.Hq, dqb = dq1 / p.Hq;
+
+    int next_step = step_lo;
+    auto issue = [&](int stage) {
+        char* sA = smem + stage * STAGE;
+        char* sB = sA + TILE;
+        const int mbase = next_step * KD;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = mbase + prow[j];
+            const bool m_ok = m < p.M;
+            // dy piece: row m, channels n0 + lvec*VE ...
+            const int n = n0 + lvec[j] * VE;
+            unsigned long long ga = a_dy + ((unsigned long long)(unsigned)m * (unsigned)p.ldy + (unsigned)n) * sizeof(T);
+            ga = (m_ok && n + VE <= p.ldy) ? ga : a_zero;
+            __builtin_amdgcn_global_load_lds((gbl_vptr)ga, (lds_vptr)(sA + (wave * 4 + j) * 1024), 16, 0, 0);
+            // input piece: tap-shifted pixel, channels c0 + lvec*VE ...
+            const int iy = tyq[j] * p.sy + dyo, ix = txq[j] * p.sx + dxo;
+            const int c = c0 + lvec[j] * VE;
+            const bool ok = m_ok && c < C && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const bool first = c < p.C1;
+            const unsigned pix = (unsigned)((tb[j] * p.Hi + iy) * p.Wi + ix);
+            unsigned long long gb = (first ? a_in1 : a_in2) +
+                                    ((unsigned long long)pix * (unsigned)(first ? p.C1 : p.C2) + (unsigned)(first ? c : c - p.C1)) * sizeof(T);
+            gb = ok ? gb : a_zero;
+            __builtin_amdgcn_global_load_lds((gbl_vptr)gb, (lds_vptr)(sB + (wave * 4 + j) * 1024), 16, 0, 0);
+            // advance this row by KD pixels
+            int x = txq[j] + dqx, y = tyq[j] + dqy, b = tb[j] + dqb;
+            if (x >= p.Wq) { x -= p.Wq; ++y; }
+            if (y >= p.Hq) { y -= p.Hq; ++b; }
+            txq[j] = x; tyq[j] = y; tb[j] = b;
+        }
+        ++next_step;
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bias_acc = 0.f;
+    const bool do_bias = p.dbias != nullptr && blockIdx.y == 0 && tid < 128;
+
+    const int nsteps = step_hi - step_lo;
+    if (nsteps > 0) issue(0);
+    for (int s = 0; s < nsteps; ++s) {
+        const int cur = s & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // step s of every wave has landed; stage cur^1 is free again
+        if (s + 1 < nsteps) issue(cur ^ 1);
+        const char* sA = smem + cur * STAGE;
+        const char* sB = sA + TILE;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                bf16x8 fa[4], fb[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) fa[it] = tr_frag2(sA, sub * 32, wn * 64 + it * 16, lane);
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) fb[jt] = tr_frag2(sB, sub * 32, wc * 64 + jt * 16, lane);
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt)
+                        acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[it], fb[jt], acc[it][jt], 0, 0, 0);
+            }
+        } else {
+            const int g = lane >> 4, il = lane & 15;
+#pragma unroll
+            for (int ss = 0; ss < KD / 4; ++ss) {
+                float fa[4], fb[4];
+                const int row = 4 * ss + g;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) fa[it] = *(const float*)(sA + wg2_off<float>(row, wn * 64 + it * 16 + il));
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) fb[jt] = *(const float*)(sB + wg2_off<float>(row, wc * 64 + jt * 16 + il));
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt)
+                        acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[it], fb[jt], acc[it][jt], 0, 0, 0);
+            }
+        }
+        if (do_bias) {
+#pragma unroll 8
+            for (int r = 0; r < KD; ++r) bias_acc += Elem<T>::ld((const T*)(sA + wg2_off<T>(r, tid)));
+        }
+    }
+
+    const int g = lane >> 4, il = lane & 15;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn * 64 + it * 16 + 4 * g + r;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                const int c = c0 + wc * 64 + jt * 16 + il;
+                if (c < C) atomicAdd(p.dw + (size_t)n * p.ldw + (size_t)t * C + c, acc[it][jt][r]);
+            }
+        }
+    if (do_bias && n0 + tid < p.N) atomicAdd(p.dbias + n0 + tid, bias_acc);
+}
+
+int g_wgrad_variant = 2;
+
+template <typename T>
+int launch_wgrad(WgP& p, int splitk_req, bool v2_ok, hipStream_t st) {
+    const bool v2 = v2_ok && g_wgrad_variant == 2;
+    const int KD = v2 ? Wg2Cfg<T>::KD : WgCfg<T>::KD;
     const int C = p.C1 + p.C2;
     p.csteps_c = cdiv(C, 128);
     p.total_steps = cdiv(p.M, KD);
     const int tiles = cdiv(p.N, 128) * p.T * p.csteps_c;
     int splitk = splitk_req;
-    if (splitk <= 0) {  // aim at ~1024 workgroups, at least 4 k-steps per split
+    if (splitk <= 0) {  // aim at ~1024 workgroups, at least 4 k-steps (v1) / 2 k-steps (v2) per split
         splitk = cdiv(1024, tiles);
-        const int maxsplit = p.total_steps / 4 > 0 ? p.total_steps / 4 : 1;
+        const int min_steps = v2 ? 2 : 4;
+        const int maxsplit = p.total_steps / min_steps > 0 ? p.total_steps / min_steps : 1;
         if (splitk > maxsplit) splitk = maxsplit;
         if (splitk < 1) splitk = 1;
     }
     p.steps_per_split = cdiv(p.total_steps, splitk);
     splitk = cdiv(p.total_steps, p.steps_per_split);
     dim3 grid(cdiv(p.N, 128), p.T * p.csteps_c, splitk);
-    hipLaunchKernelGGL((conv_wgrad_kernel<T>), grid, dim3(256), 0, st, p);
+    if (v2) {
+        constexpr int bytes = 4 * Wg2Cfg<T>::KD * Wg2Cfg<T>::RB;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) { dm_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv_wgrad2_kernel<T>), grid, dim3(256), bytes, st, p);
+    } else {
+        hipLaunchKernelGGL((conv_wgrad_kernel<T>), grid, dim3(256), 0, st, p);
+    }
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
 
 }  // namespace
+
+extern "C" int dm_set_wgrad_variant(int variant) {
+    DM_CHECK_ARG(variant == 1 || variant == 2, "dm_set_wgrad_variant: 1 (register staging) or 2 (LDS-DMA)");
+    g_wgrad_variant = variant;
+    return DM_OK;
+}
 
 extern "C" int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream) {
     DM_CHECK_ARG(d != nullptr, "dm_conv_wgrad: null descriptor");
@@ -219,6 +422,11 @@ extern "C" int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream) {
     p.T = d->T; p.KW = d->KW; p.ty = d->ty; p.tx = d->tx; p.oy0 = d->oy0; p.ox0 = d->ox0;
     p.Ho = d->Ho; p.Wo = d->Wo; p.osy = d->osy; p.osx = d->osx; p.ooy = d->ooy; p.oox = d->oox;
     p.N = d->N; p.ldy = d->ldy; p.ldw = d->ldw; p.M = (int)M;
-    if (d->dtype == DM_BF16) return launch_wgrad<bf16>(p, d->splitk, (hipStream_t)stream);
-    return launch_wgrad<float>(p, d->splitk, (hipStream_t)stream);
+    // v2 (LDS-DMA) needs the identity dy mapping and 32-bit pixel / element arithmetic
+    const int64_t in_elems = (int64_t)d->B * d->Hi * d->Wi * (d->C1 > d->C2 ? d->C1 : d->C2);
+    const bool v2_ok = d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0 && d->Ho == d->Hq && d->Wo == d->Wq &&
+                       in_elems < (1ll << 31) && M * d->ldy < (1ll << 32) && ((uintptr_t)d->dy & 15) == 0 &&
+                       ((uintptr_t)d->in1 & 15) == 0 && ((uintptr_t)d->in2 & 15) == 0;
+    if (d->dtype == DM_BF16) return launch_wgrad<bf16>(p, d->splitk, v2_ok, (hipStream_t)stream);
+    return launch_wgrad<float>(p, d->splitk, v2_ok, (hipStream_t)stream);
 }

@@ -451,21 +451,45 @@ def _mfma_linear(M, K, N):
     return K % 4 == 0 and N % 4 == 0
 
 
+def _lin_fwd(x, w, b, y):
+    """y[M][N] = x[M][K] w[N][K]^T + b, fp32.  MFMA path: the rows of x are "pixels" of a 1x1 image, w is already [N][K]."""
+    M, K = x.shape
+    N = w.shape[0]
+    if _mfma_linear(M, K, N):
+        _conv_call(x, None, ptr(w), K, y, dtype=torch.float32, B=M, Hi=1, Wi=1, C1=K, C2=0, Hq=1, Wq=1, sy=1, sx=1, T=1,
+                   KW=1, ty=1, tx=1, oy0=0, ox0=0, Ho=1, Wo=1, N=N, shift=b)
+    else:
+        call("dm_linear_fwd", ptr(x), ptr(w), ptr(b), ptr(y), M, K, N, ACT_NONE)
+
+
+def _lin_bwd(x, w, g, dx, dw, db):
+    """dx = g w (overwritten), dw += g^T x, db += colsum(g); any of dx/dw/db may be None."""
+    M, K = x.shape
+    N = w.shape[0]
+    if not _mfma_linear(M, K, N):
+        call("dm_linear_bwd", ptr(x), ptr(w), ptr(g), ptr(dx), ptr(dw), ptr(db), M, K, N)
+        return
+    if dx is not None:
+        def build():
+            wt = _empty((K, N), torch.float32, w)
+            call("dm_pack_wT", ptr(w), ptr(wt), L.DM_F32, N, 1, K, 1, None, N)
+            return wt
+        wt = _cached(("linT",), w, build)
+        _conv_call(g, None, ptr(wt), N, dx, dtype=torch.float32, B=M, Hi=1, Wi=1, C1=N, C2=0, Hq=1, Wq=1, sy=1, sx=1,
+                   T=1, KW=1, ty=1, tx=1, oy0=0, ox0=0, Ho=1, Wo=1, N=K)
+    if dw is not None or db is not None:
+        tgt = dw if dw is not None else _zeros((N, K), torch.float32, x)
+        _wgrad_call(g, x, None, tgt, db, dtype=torch.float32, B=M, Hi=1, Wi=1, C1=K, C2=0, Hq=1, Wq=1, sy=1, sx=1, T=1,
+                    KW=1, ty=1, tx=1, oy0=0, ox0=0, Ho=1, Wo=1, N=N, ldy=N, ldw=K)
+
+
 class Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
         L.require_device(x, w)
-        x = x.contiguous()
-        M, K = x.shape
-        N = w.shape[0]
-        w = w.contiguous()
-        y = _empty((M, N), torch.float32, x)
-        if _mfma_linear(M, K, N):
-            # exact-fp32 MFMA GEMM: the rows of x are "pixels" of a 1x1 image, w is already [N][K]
-            _conv_call(x, None, ptr(w), K, y, dtype=torch.float32, B=M, Hi=1, Wi=1, C1=K, C2=0, Hq=1, Wq=1, sy=1, sx=1, T=1,
-                       KW=1, ty=1, tx=1, oy0=0, ox0=0, Ho=1, Wo=1, N=N, shift=b)
-        else:
-            call("dm_linear_fwd", ptr(x), ptr(w), ptr(b), ptr(y), M, K, N, ACT_NONE)
+        x, w = x.contiguous(), w.contiguous()
+        y = _empty((x.shape[0], w.shape[0]), torch.float32, x)
+        _lin_fwd(x, w, b, y)
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
         return y
@@ -476,29 +500,10 @@ class Linear(torch.autograd.Function):
         g = g.contiguous()
         M, K = x.shape
         N = w.shape[0]
-        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        need_db = ctx.has_b and ctx.needs_input_grad[2]
-        dx = _empty((M, K), torch.float32, x) if need_dx else None
-        dw = _zeros((N, K), torch.float32, x) if need_dw else None
-        db = _zeros((N,), torch.float32, x) if need_db else None
-        if _mfma_linear(M, K, N):
-            if need_dx:
-                def build():
-                    wt = _empty((K, N), torch.float32, w)
-                    call("dm_pack_wT", ptr(w), ptr(wt), L.DM_F32, N, 1, K, 1, None, N)
-                    return wt
-                wt = _cached(("linT",), w, build)
-                _conv_call(g, None, ptr(wt), N, dx, dtype=torch.float32, B=M, Hi=1, Wi=1, C1=N, C2=0, Hq=1, Wq=1, sy=1, sx=1,
-                           T=1, KW=1, ty=1, tx=1, oy0=0, ox0=0, Ho=1, Wo=1, N=K)
-            if need_dw or need_db:
-                if dw is None:
-                    dw = _zeros((N, K), torch.float32, x)
-                _wgrad_call(g, x, None, dw, db, dtype=torch.float32, B=M, Hi=1, Wi=1, C1=K, C2=0, Hq=1, Wq=1, sy=1, sx=1, T=1,
-                            KW=1, ty=1, tx=1, oy0=0, ox0=0, Ho=1, Wo=1, N=N, ldy=N, ldw=K)
-                if not need_dw:
-                    dw = None
-        else:
-            call("dm_linear_bwd", ptr(x), ptr(w), ptr(g), ptr(dx), ptr(dw), ptr(db), M, K, N)
+        dx = _empty((M, K), torch.float32, x) if ctx.needs_input_grad[0] else None
+        dw = _zeros((N, K), torch.float32, x) if ctx.needs_input_grad[1] else None
+        db = _zeros((N,), torch.float32, x) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        _lin_bwd(x, w, g, dx, dw, db)
         return dx, dw, db
 
 
@@ -594,9 +599,9 @@ class SeResidual(torch.autograd.Function):
         call("dm_pool_hw", ptr(x2), dt(x2), B, H * W, Cc, ptr(y))
         hid, gh = _empty((B, R), torch.float32, x2), _empty((B, R), torch.float32, x2)
         logit, sg = _empty((B, Cc), torch.float32, x2), _empty((B, Cc), torch.float32, x2)
-        call("dm_linear_fwd", ptr(y), ptr(w1), None, ptr(hid), B, Cc, R, ACT_NONE)
+        _lin_fwd(y, w1, None, hid)
         call("dm_act_fwd", ptr(hid), ptr(gh), B * R, ACT_GELU)
-        call("dm_linear_fwd", ptr(gh), ptr(w2), None, ptr(logit), B, R, Cc, ACT_NONE)
+        _lin_fwd(gh, w2, None, logit)
         call("dm_act_fwd", ptr(logit), ptr(sg), B * Cc, ACT_SIGMOID)
         call("dm_scale_residual_fwd", ptr(x2), ptr(res), ptr(sg), ptr(out), dt(x2), B, H * W, Cc, inv)
         ctx.save_for_backward(x2, y, hid, gh, logit, sg, w1, w2)
@@ -618,9 +623,9 @@ class SeResidual(torch.autograd.Function):
         dw1, dw2 = _zeros((R, Cc), torch.float32, g), _zeros((Cc, R), torch.float32, g)
         call("dm_scale_residual_bwd_reduce", ptr(g), ptr(x2), dt(dtype), B, H * W, Cc, inv, ptr(dsg))
         call("dm_act_bwd", ptr(logit), ptr(dsg), ptr(dlogit), B * Cc, ACT_SIGMOID)
-        call("dm_linear_bwd", ptr(gh), ptr(w2), ptr(dlogit), ptr(dgh), ptr(dw2), None, B, R, Cc)
+        _lin_bwd(gh, w2, dlogit, dgh, dw2, None)
         call("dm_act_bwd", ptr(hid), ptr(dgh), ptr(dhid), B * R, ACT_GELU)
-        call("dm_linear_bwd", ptr(y), ptr(w1), ptr(dhid), ptr(dy), ptr(dw1), None, B, Cc, R)
+        _lin_bwd(y, w1, dhid, dy, dw1, None)
         call("dm_scale_residual_bwd_apply", ptr(g), ptr(sg), ptr(dy), ptr(dx2), ptr(dres), dt(dtype), B, H * W, Cc, inv)
         return dx2, dres, dw1, dw2, None
 

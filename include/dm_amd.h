@@ -74,6 +74,7 @@ typedef struct DmWgrad {
     int32_t N, ldy, ldw, splitk;
 } DmWgrad;
 int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream);
+int dm_set_wgrad_variant(int variant);   /* tuning knob: 1 = register staging, 2 = LDS-DMA (default) */
 
 /* Weight repacks. src is the fp32 master in physical layout [N][T][C] (= torch channels_last of OIHW).
  *  dm_pack_w:   dst[n][t][cp]      = c < C ? src[n][t][c] : 0          (cast + channel pad), dst dtype
