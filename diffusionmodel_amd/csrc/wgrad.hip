@@ -23,6 +23,7 @@ struct WgP {
     const char* dy; const char* in1; const char* in2; float* dw; float* dbias;
     int B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0;
     int Ho, Wo, osy, osx, ooy, oox, N, ldy, ldw, M, csteps_c, steps_per_split, total_steps;
+    int gx, gy, gz;   // logical grid of the v2 kernel (launched 1-D, see the XCD mapping there)
 };
 
 template <typename T> struct WgCfg;
@@ -222,15 +223,32 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1, wc = wave >> 1;
     const int C = p.C1 + p.C2;
-    const int n0 = blockIdx.x * 128;
-    const int t = blockIdx.y / p.csteps_c, c0 = (blockIdx.y - t * p.csteps_c) * 128;
+    // XCD-aware decode of the 1-D grid: workgroups are dealt round-robin over the 8 XCDs, so with
+    // id = xcd + 8*(tile + ntiles*zhi) and pixel-split z = 8*zhi + xcd, ALL tap / channel tiles of one pixel
+    // split run on ONE XCD back to back: the 9 taps re-read the same dy / input rows out of that L2.
+    const int ntile = p.gx * p.gy;
+    // (only when there are >= 8 pixel splits; with fewer, a plain decode keeps all XCDs busy)
+    const int lin = blockIdx.x;
+    int tile, bz;
+    if (p.gz >= 8) {
+        const int xcd = lin & 7, rest = lin >> 3;
+        tile = rest % ntile;
+        bz = (rest / ntile) * 8 + xcd;
+    } else {
+        tile = lin % ntile;
+        bz = lin / ntile;
+    }
+    if (bz >= p.gz) return;
+    const int bx = tile % p.gx, by = tile / p.gx;
+    const int n0 = bx * 128;
+    const int t = by / p.csteps_c, c0 = (by - t * p.csteps_c) * 128;
     const int ky = t / p.KW, kx = t - ky * p.KW;
     const int dyo = ky * p.ty + p.oy0, dxo = kx * p.tx + p.ox0;
     unsigned long long a_dy = (unsigned long long)p.dy, a_in1 = (unsigned long long)p.in1;
     unsigned long long a_in2 = (unsigned long long)(p.in2 ? p.in2 : p.in1), a_zero = (unsigned long long)g_wg_zero_page;
     asm volatile("" : "+s"(a_dy), "+s"(a_in1), "+s"(a_in2), "+s"(a_zero));
 
-    const int step_lo = blockIdx.z * p.steps_per_split;
+    const int step_lo = bz * p.steps_per_split;
     const int step_hi = min(step_lo + p.steps_per_split, p.total_steps);
 
     // ---- per-lane DMA geometry: a piece = RPP rows; lane -> (row in piece, physical slot) -> logical vector
@@ -293,7 +311,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bias_acc = 0.f;
-    const bool do_bias = p.dbias != nullptr && blockIdx.y == 0 && tid < 128;
+    const bool do_bias = p.dbias != nullptr && by == 0 && tid < 128;
 
     const int nsteps = step_hi - step_lo;
     if (nsteps > 0) issue(0);
@@ -386,7 +404,9 @@ int launch_wgrad(WgP& p, int splitk_req, bool v2_ok, hipStream_t st) {
             if (e != hipSuccess) { dm_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
             attr_set = true;
         }
-        hipLaunchKernelGGL((conv_wgrad2_kernel<T>), grid, dim3(256), bytes, st, p);
+        p.gx = grid.x; p.gy = grid.y; p.gz = grid.z;
+        const unsigned total = grid.x * grid.y * (grid.z >= 8 ? (grid.z + 7) / 8 * 8 : grid.z);
+        hipLaunchKernelGGL((conv_wgrad2_kernel<T>), dim3(total), dim3(256), bytes, st, p);
     } else {
         hipLaunchKernelGGL((conv_wgrad_kernel<T>), grid, dim3(256), 0, st, p);
     }
