@@ -69,6 +69,30 @@ __device__ inline float act_grad(float x, int act) {
     }
 }
 
+// bf16-mode GELU: Abramowitz-Stegun 7.1.26 erf (|err| <= 1.5e-7, far below bf16 rounding) on v_rcp/v_exp —
+// ~20 VALU instead of libm erff's ~70, which is what made the BN+GELU streaming kernels VALU-bound, not
+// HBM-bound.  The exponential exp(-x^2/2) is shared with the Gaussian pdf of the derivative.  fp32 mode
+// keeps libm erff (the 1e-4 parity mode).
+__device__ inline void gelu_parts_fast(float x, float& cdf, float& e) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    e = __expf(-z * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    cdf = 0.5f * (1.0f + copysignf(1.0f - poly * e, x));
+}
+template <typename T> __device__ inline float act_apply_t(float x, int act) {
+    if constexpr (sizeof(T) == 2) {
+        if (act == DM_ACT_GELU) { float cdf, e; gelu_parts_fast(x, cdf, e); return x * cdf; }
+    }
+    return act_apply(x, act);
+}
+template <typename T> __device__ inline float act_grad_t(float x, int act) {
+    if constexpr (sizeof(T) == 2) {
+        if (act == DM_ACT_GELU) { float cdf, e; gelu_parts_fast(x, cdf, e); return cdf + x * 0.39894228040143267794f * e; }
+    }
+    return act_grad(x, act);
+}
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -159,7 +159,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 
             if (nb4 >= p.N) continue;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = act_apply(acc[nt][mt][r], p.act);
+            for (int r = 0; r < 4; ++r) v[r] = act_apply_t<T>(acc[nt][mt][r], p.act);
             if (p.out_nchw) {
                 float* o = (float*)p.out;
 #pragma unroll

@@ -6,20 +6,19 @@
 
 namespace {
 
-constexpr int CS_ROWS = 128;  // rows per block in column-statistics kernels (small slabs: enough workgroups to hide HBM latency)
 
 // ---------------------------------------------------------------------------------------------
-// Column partial reduction skeleton: block handles rows [r0, r0+CS_ROWS) of an [M][C] matrix.
+// Column partial reduction skeleton: block handles rows [r0, r0+rows_per_block) of an [M][C] matrix.
 // Thread (cv, rl): column vector cv (V elements), row lane rl; LDS folds the row lanes.
 // F: functor object: init(col0) loads whatever is per-column (kept in registers for the whole row loop),
 //    row(r, col0, v1[V], v2[V]) produces the two quantities to sum.
 // ---------------------------------------------------------------------------------------------
 template <int V, typename F>
-__device__ inline void col_partial(int M, int C, float* p1, float* p2, F& f) {
+__device__ inline void col_partial(int M, int C, int rows_per_block, float* p1, float* p2, F& f) {
     __shared__ float red[2][2048];
     const int CVt = (C + V - 1) / V;  // column vectors in total
-    const int r0 = blockIdx.x * CS_ROWS;
-    const int r1 = min(r0 + CS_ROWS, M);
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(r0 + rows_per_block, M);
     for (int cbase = 0; cbase < CVt; cbase += 256) {
         const int ncv = min(256, CVt - cbase);     // column vectors in this chunk
         const int RL = 256 / ncv;                  // row lanes (>= 1)
@@ -83,9 +82,9 @@ struct StatsF {
     }
 };
 template <typename T, int V>
-__global__ __launch_bounds__(256) void col_stats_kernel(const T* z, int M, int C, float* psum, float* psq) {
+__global__ __launch_bounds__(256) void col_stats_kernel(const T* z, int M, int C, int rpb, float* psum, float* psq) {
     StatsF<T, V> f{z, C};
-    col_partial<V>(M, C, psum, psq, f);
+    col_partial<V>(M, C, rpb, psum, psq, f);
 }
 
 // per-thread channel parameters held in registers by the streaming BN kernels
@@ -93,11 +92,23 @@ template <int V>
 struct BnParams {
     float mu[V], rs[V], gm[V], bt[V];
     __device__ inline void load(int c0, int C, const float* mean, const float* rstd, const float* gamma, const float* beta) {
+        if constexpr (V % 4 == 0) {       // vector path: c0 is a multiple of V, C a multiple of V -> aligned float4 loads
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            const int c = c0 + k < C ? c0 + k : C - 1;
-            mu[k] = mean[c]; rs[k] = rstd[c];
-            gm[k] = gamma ? gamma[c] : 1.f; bt[k] = beta ? beta[c] : 0.f;
+            for (int k = 0; k < V; k += 4) {
+                const f32x4 m4 = *(const f32x4*)(mean + c0 + k), r4 = *(const f32x4*)(rstd + c0 + k);
+                f32x4 g4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+                if (gamma) g4 = *(const f32x4*)(gamma + c0 + k);
+                if (beta) b4 = *(const f32x4*)(beta + c0 + k);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { mu[k + j] = m4[j]; rs[k + j] = r4[j]; gm[k + j] = g4[j]; bt[k + j] = b4[j]; }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const int c = c0 + k < C ? c0 + k : C - 1;
+                mu[k] = mean[c]; rs[k] = rstd[c];
+                gm[k] = gamma ? gamma[c] : 1.f; bt[k] = beta ? beta[c] : 0.f;
+            }
         }
     }
 };
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* z, T* y, int64
         float v[V];
         load_cols<T, V>(z + i * V, v);
 #pragma unroll
-        for (int k = 0; k < V; ++k) v[k] = act_apply((v[k] - P.mu[k]) * P.rs[k] * P.gm[k] + P.bt[k], act);
+        for (int k = 0; k < V; ++k) v[k] = act_apply_t<T>((v[k] - P.mu[k]) * P.rs[k] * P.gm[k] + P.bt[k], act);
         store_cols<T, V>(y + i * V, v);
     }
 }
@@ -168,7 +179,7 @@ struct BwdRedF {
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const float xh = (zz[i] - P.mu[i]) * P.rs[i];
-            const float g = dd[i] * act_grad(xh * P.gm[i] + P.bt[i], act);
+            const float g = dd[i] * act_grad_t<T>(xh * P.gm[i] + P.bt[i], act);
             v1[i] = g;
             v2[i] = g * xh;
         }
@@ -177,9 +188,9 @@ struct BwdRedF {
 template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* z, const T* dy, int M, int C, const float* mean,
                                                             const float* rstd, const float* gamma, const float* beta,
-                                                            int act, float* p1, float* p2) {
+                                                            int act, int rpb, float* p1, float* p2) {
     BwdRedF<T, V> f{z, dy, C, mean, rstd, gamma, beta, act, {}};
-    col_partial<V>(M, C, p1, p2, f);
+    col_partial<V>(M, C, rpb, p1, p2, f);
 }
 
 template <typename T, int V>
@@ -203,7 +214,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* z, const T* 
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             const float xh = (zz[k] - P.mu[k]) * P.rs[k];
-            const float g = dd[k] * act_grad(xh * P.gm[k] + P.bt[k], act);
+            const float g = dd[k] * act_grad_t<T>(xh * P.gm[k] + P.bt[k], act);
             zz[k] = P.gm[k] * P.rs[k] * (g - m1[k] - xh * m2[k]);
         }
         store_cols<T, V>(dz + i * V, zz);
@@ -299,6 +310,20 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* x, const T* dy, T*
     }
 }
 
+// grid of the per-thread-column streaming kernels: >= 8 vectors per thread (the 4 x V channel parameters a
+// thread keeps in registers are then amortised), at most 8 workgroups per CU, at least one pass over a row
+int stream_grid(int64_t nvec, int cv) {
+    int64_t g = (nvec + 256 * 8 - 1) / (256 * 8);
+    if (g > 2048) g = 2048;
+    const int64_t need = (cv + 255) / 256;
+    if (g < need) g = need;
+    return (int)(g < 1 ? 1 : g);
+}
+
+// rows per workgroup of the column-reduction kernels: small matrices get thinner slabs so that the grid
+// still covers the chip
+int cs_rows(int M) { return M >= 65536 ? 128 : (M >= 16384 ? 64 : 32); }
+
 template <typename T>
 bool vec_ok(int C, const void* a, const void* b = nullptr, const void* c = nullptr) {
     const uintptr_t m = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c;
@@ -307,14 +332,14 @@ bool vec_ok(int C, const void* a, const void* b = nullptr, const void* c = nullp
 
 }  // namespace
 
-extern "C" int dm_colstat_blocks(int M) { return cdiv(M, CS_ROWS); }
+extern "C" int dm_colstat_blocks(int M) { return cdiv(M, cs_rows(M)); }
 
 extern "C" int dm_col_stats(const void* z, int dtype, int M, int C, float* psum, float* psq, dm_stream_t s) {
     DM_CHECK_ARG(z && psum && psq && M > 0 && C > 0, "dm_col_stats: bad arguments");
-    const int grid = cdiv(M, CS_ROWS);
+    const int rpb = cs_rows(M), grid = cdiv(M, rpb);
     DM_DISPATCH_DTYPE(dtype, {
-        if (vec_ok<T>(C, z)) hipLaunchKernelGGL((col_stats_kernel<T, Elem<T>::VE>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, M, C, psum, psq);
-        else hipLaunchKernelGGL((col_stats_kernel<T, 1>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, M, C, psum, psq);
+        if (vec_ok<T>(C, z)) hipLaunchKernelGGL((col_stats_kernel<T, Elem<T>::VE>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, M, C, rpb, psum, psq);
+        else hipLaunchKernelGGL((col_stats_kernel<T, 1>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, M, C, rpb, psum, psq);
     });
     DM_LAUNCH_CHECK();
     return DM_OK;
@@ -344,10 +369,10 @@ extern "C" int dm_bn_act_fwd(const void* z, void* y, int dtype, int M, int C, co
         if (vec_ok<T>(C, z, y)) {
             constexpr int V = Elem<T>::VE;
             const int64_t nvec = (int64_t)M * C / V;
-            hipLaunchKernelGGL((bn_act_fwd_kernel<T, V>), dim3(grid_for(nvec, 256)), dim3(256), 0, (hipStream_t)s, (const T*)z, (T*)y, nvec, C / V, mean, rstd, gamma, beta, act);
+            hipLaunchKernelGGL((bn_act_fwd_kernel<T, V>), dim3(stream_grid(nvec, C / V)), dim3(256), 0, (hipStream_t)s, (const T*)z, (T*)y, nvec, C / V, mean, rstd, gamma, beta, act);
         } else {
             const int64_t nvec = (int64_t)M * C;
-            hipLaunchKernelGGL((bn_act_fwd_kernel<T, 1>), dim3(grid_for(nvec, 256)), dim3(256), 0, (hipStream_t)s, (const T*)z, (T*)y, nvec, C, mean, rstd, gamma, beta, act);
+            hipLaunchKernelGGL((bn_act_fwd_kernel<T, 1>), dim3(stream_grid(nvec, C)), dim3(256), 0, (hipStream_t)s, (const T*)z, (T*)y, nvec, C, mean, rstd, gamma, beta, act);
         }
     });
     DM_LAUNCH_CHECK();
@@ -357,10 +382,10 @@ extern "C" int dm_bn_act_fwd(const void* z, void* y, int dtype, int M, int C, co
 extern "C" int dm_bn_act_bwd_reduce(const void* z, const void* dy, int dtype, int M, int C, const float* mean, const float* rstd,
                                     const float* gamma, const float* beta, int act, float* p1, float* p2, dm_stream_t s) {
     DM_CHECK_ARG(z && dy && mean && rstd && p1 && p2 && M > 0 && C > 0, "dm_bn_act_bwd_reduce: bad arguments");
-    const int grid = cdiv(M, CS_ROWS);
+    const int rpb = cs_rows(M), grid = cdiv(M, rpb);
     DM_DISPATCH_DTYPE(dtype, {
-        if (vec_ok<T>(C, z, dy)) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, Elem<T>::VE>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, p1, p2);
-        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, p1, p2);
+        if (vec_ok<T>(C, z, dy)) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, Elem<T>::VE>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2);
     });
     DM_LAUNCH_CHECK();
     return DM_OK;
@@ -375,10 +400,10 @@ extern "C" int dm_bn_act_bwd_apply(const void* z, const void* dy, void* dz, int 
         if (vec_ok<T>(C, z, dy, dz)) {
             constexpr int V = Elem<T>::VE;
             const int64_t nvec = (int64_t)M * C / V;
-            hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V>), dim3(grid_for(nvec, 256)), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, (T*)dz, nvec, C / V, invM, mean, rstd, gamma, beta, act, s1, s2);
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V>), dim3(stream_grid(nvec, C / V)), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, (T*)dz, nvec, C / V, invM, mean, rstd, gamma, beta, act, s1, s2);
         } else {
             const int64_t nvec = (int64_t)M * C;
-            hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), dim3(grid_for(nvec, 256)), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, (T*)dz, nvec, C, invM, mean, rstd, gamma, beta, act, s1, s2);
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), dim3(stream_grid(nvec, C)), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, (T*)dz, nvec, C, invM, mean, rstd, gamma, beta, act, s1, s2);
         }
     });
     DM_LAUNCH_CHECK();
