@@ -376,6 +376,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgP p) {
 }
 
 int g_wgrad_variant = 2;
+int g_wgrad_blocks = 1024;   // workgroups the pixel split aims at (more splits = more parallelism but more fp32 atomic traffic)
 
 template <typename T>
 int launch_wgrad(WgP& p, int splitk_req, bool v2_ok, hipStream_t st) {
@@ -387,7 +388,7 @@ int launch_wgrad(WgP& p, int splitk_req, bool v2_ok, hipStream_t st) {
     const int tiles = cdiv(p.N, 128) * p.T * p.csteps_c;
     int splitk = splitk_req;
     if (splitk <= 0) {  // aim at ~1024 workgroups, at least 4 k-steps (v1) / 2 k-steps (v2) per split
-        splitk = cdiv(1024, tiles);
+        splitk = cdiv(g_wgrad_blocks, tiles);
         const int min_steps = v2 ? 2 : 4;
         const int maxsplit = p.total_steps / min_steps > 0 ? p.total_steps / min_steps : 1;
         if (splitk > maxsplit) splitk = maxsplit;
@@ -417,6 +418,8 @@ int launch_wgrad(WgP& p, int splitk_req, bool v2_ok, hipStream_t st) {
 }  // namespace
 
 extern "C" int dm_set_wgrad_variant(int variant) {
+    // variant >= 64 sets the workgroup target of the pixel split instead (tuning)
+    if (variant >= 64) { g_wgrad_blocks = variant; return DM_OK; }
     DM_CHECK_ARG(variant == 1 || variant == 2, "dm_set_wgrad_variant: 1 (register staging) or 2 (LDS-DMA)");
     g_wgrad_variant = variant;
     return DM_OK;
