@@ -167,8 +167,20 @@ def main():
     dom = "conv_igemm"
     peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
     ach = fl[dom][0] / max(fl[dom][1], 1e-12) / 1e12
+    # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes over this same
+    # command (they cannot be collected from inside the process); the committed summary is quoted when present
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+            pmc = json.load(f)["kernels"].get("conv_igemm2<bf16>" if dtype == torch.bfloat16 else "", None)
+        if pmc and args.n_feat == 128 and args.size == 64 and args.batch == 64:
+            traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)"
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<%s> (fwd + dgrad launches)" % args.dtype,
-                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (avg)", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": "A read once + weights + output written once = 67-201 MB on the 64^2 layers",
                 "launches": fl[dom][2], "avg_launch_us": round(fl[dom][1] / max(fl[dom][2], 1) * 1e6, 2),
                 "algorithmic_tflop_per_step": round(fl[dom][0] / args.steps / 1e12, 4),
                 "wgrad": {"achieved": round(fl["conv_wgrad"][0] / max(fl["conv_wgrad"][1], 1e-12) / 1e12, 2),
