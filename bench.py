@@ -105,11 +105,13 @@ def main():
     ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=8)
     ap.add_argument("--cpu-iters", dest="cpu_iters", type=int, default=2)
     ap.add_argument("--buckets", type=int, default=4)
+    ap.add_argument("--force-dp", dest="force_dp", action="store_true",
+                    help="run the RCCL gradient all-reduce path even with one rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
     import diffusionmodel_amd as D
     from diffusionmodel_amd import ops, parallel
-    rank, world, local = parallel.init_from_env("nccl")
+    rank, world, local = parallel.init_from_env("nccl", force=args.force_dp)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
@@ -120,9 +122,14 @@ def main():
     ddpm = D.DDPM(net, (1e-4, 0.02), 1000, dev, drop_prob=0.1)
     ddpm.train()
     opt = D.FusedAdamW(ddpm.parameters(), lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, grad_scale=1.0 / world)
-    reducer = parallel.GradReducer(opt.flat_g, n_buckets=args.buckets) if world > 1 else None
-    if world > 1:
+    use_dp = world > 1 or args.force_dp
+    reducer = parallel.GradReducer(opt.flat_g, n_buckets=args.buckets) if use_dp else None
+    if use_dp:
         parallel.broadcast_parameters(opt.flat_p)
+        ops.bump_weight_epoch()
+    # identical weights, but every rank draws its own timesteps / noise / keep-masks on its own data shard
+    torch.manual_seed(1234 + rank)
+    ddpm.rng_seed = 1234 + rank
     x, c, am = synthetic_batch(args.batch, args.size, 4, dev, seed=rank)
 
     def train_step():
@@ -135,7 +142,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if use_dp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -149,7 +156,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
-    if world > 1:
+    if use_dp:
         tt = torch.tensor([elapsed], device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -219,7 +226,7 @@ def main():
                           "parallelism": "dp%d" % world, "samples_per_s": round(value * args.batch, 2)},
                "loss": final_loss, "roofline": roofline, "cpu_baseline": cpu, "sample": sample}
         print(json.dumps(out))
-    if world > 1:
+    if use_dp:
         torch.distributed.destroy_process_group()
 
 

@@ -16,12 +16,12 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force=False):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -55,12 +55,13 @@ class GradReducer:
         self.group = group
         self.bounds = bucket_bounds(flat_grad.numel(), n_buckets)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized()
         self._works = []
         self._stream = torch.cuda.Stream() if flat_grad.is_cuda else None
 
     def start(self):
         """Launch the bucket all-reduces (asynchronously on a side stream for device tensors)."""
-        if self.world == 1:
+        if not self.active:
             return
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())
