@@ -77,6 +77,8 @@ _PROTOS = {
     "dm_add": [vp, vp, vp, i32, i64],
     "dm_mask_axpy": [vp, vp, vp, f32, vp, i32, i64, i32],
     "dm_scatter_copy": [vp, i32, i32],
+    "dm_image_moments": [vp, vp, vp, i32, i64],
+    "dm_attn_mask": [vp, vp, i32, i32, f32, f32, f32],
     "dm_qsample": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32],
     "dm_loss_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32],
     "dm_loss_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32],

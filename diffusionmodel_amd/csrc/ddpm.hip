@@ -269,3 +269,65 @@ extern "C" int dm_scatter_copy(const int64_t* table_dev, int n_entries, int add,
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
+
+// ---- evaluation helpers (new_scripy.py:1188-1250) and attention-mask rasterisation (:533-546) ------------------
+namespace {
+// one workgroup per image pair: {sum a, sum b, sum a^2, sum b^2, sum ab, min a, min b, n} in double
+__global__ __launch_bounds__(256) void image_moments_kernel(const float* a, const float* b, double* out, int64_t n) {
+    __shared__ double red[8][4];
+    const float* pa = a + (size_t)blockIdx.x * n;
+    const float* pb = b + (size_t)blockIdx.x * n;
+    double s[5] = {0, 0, 0, 0, 0};
+    float mna = INFINITY, mnb = INFINITY;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const double x = pa[i], y = pb[i];
+        s[0] += x; s[1] += y; s[2] += x * x; s[3] += y * y; s[4] += x * y;
+        mna = fminf(mna, pa[i]); mnb = fminf(mnb, pb[i]);
+    }
+    double v[7] = {s[0], s[1], s[2], s[3], s[4], (double)mna, (double)mnb};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double other = __shfl_xor(v[k], o, 64);
+            v[k] = k < 5 ? v[k] + other : fmin(v[k], other);
+        }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 7; ++k) red[k][w] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const int k = threadIdx.x;
+        double r = red[k][0];
+        for (int j = 1; j < 4; ++j) r = k < 5 ? r + red[k][j] : fmin(r, red[k][j]);
+        out[(size_t)blockIdx.x * 8 + k] = r;
+    }
+    if (threadIdx.x == 7) out[(size_t)blockIdx.x * 8 + 7] = (double)n;
+}
+
+__global__ void attn_mask_kernel(const int32_t* boxes, float* out, int B, int S, float lo, float mid, float hi) {
+    const int64_t total = (int64_t)B * S * S;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % S), y = (int)((i / S) % S), b = (int)(i / ((int64_t)S * S));
+        const int32_t* q = boxes + 4 * b;      // x0, y0, x1, y1 (already scaled and clamped), half-open like the slice
+        float v = y >= S / 2 ? mid : lo;
+        if (y >= q[1] && y < q[3] && x >= q[0] && x < q[2]) v = hi;
+        out[i] = v;
+    }
+}
+}  // namespace
+
+extern "C" int dm_image_moments(const float* a, const float* b, double* out, int n_images, int64_t n_per_image, dm_stream_t s) {
+    DM_CHECK_ARG(a && b && out && n_images > 0 && n_per_image > 0, "dm_image_moments: bad arguments");
+    hipLaunchKernelGGL(image_moments_kernel, dim3(n_images), dim3(256), 0, ST, a, b, out, n_per_image);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_attn_mask(const int32_t* boxes, float* out, int B, int S, float lo, float mid, float hi, dm_stream_t s) {
+    DM_CHECK_ARG(boxes && out && B > 0 && S > 0, "dm_attn_mask: bad arguments");
+    hipLaunchKernelGGL(attn_mask_kernel, dim3(grid_for((int64_t)B * S * S, 256)), dim3(256), 0, ST, boxes, out, B, S, lo, mid, hi);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}

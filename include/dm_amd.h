@@ -225,6 +225,14 @@ int dm_sumsq(const float* g, int64_t n, float* out /* one float, += */, dm_strea
  * hyper = {lr, beta1, beta2, eps, weight_decay, max_norm, gscale, bias_corr1, bias_corr2} (device) */
 int dm_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hyper9, dm_stream_t s);
 
+/* Evaluation helpers of the drivers (new_scripy.py:1188-1250): per image pair (a_i, b_i), n_per_image floats each,
+ * out[i] = {sum a, sum b, sum a^2, sum b^2, sum ab, min a, min b, n} as 8 doubles — global-statistics SSIM and PSNR
+ * follow on the host (diffusionmodel_amd/metrics.py). */
+int dm_image_moments(const float* a, const float* b, double* out, int n_images, int64_t n_per_image, dm_stream_t s);
+/* Attention mask of CrackDataset (new_scripy.py:533-546): `lo` everywhere, `mid` on rows >= S/2, `hi` inside the
+ * half-open box boxes[b] = {x0, y0, x1, y1} (already scaled/clamped on the host). out [B][S][S]. */
+int dm_attn_mask(const int32_t* boxes, float* out, int B, int S, float lo, float mid, float hi, dm_stream_t s);
+
 /* multi-tensor fp32 copy/add: table_dev[e] = {src_ptr, dst_ptr, count}; gathers the small parameters'
  * gradients into the flat gradient buffer in one launch */
 int dm_scatter_copy(const int64_t* table_dev, int n_entries, int add, dm_stream_t s);

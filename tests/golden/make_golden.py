@@ -275,6 +275,7 @@ def main():
     gen_ddpm_sample(R, "sample64_T5", 64, 4, 5, 4, 2.0)
     gen_ddpm_sample(R, "sample64_T3_w0", 64, 4, 3, 8, 0.0)
     gen_mnist(M)
+    gen_metrics_and_masks(R)
     # key schema of the full-size nets (shapes only; no tensors are instantiated for the big ones)
     SCHEMA["ddpm_keys_F32_k4"] = [(k, list(v.shape)) for k, v in
                                   R.DDPM(make_ref_unet(R, 32, 4, 4), (1e-4, 0.02), 1000, "cpu").state_dict().items()]
@@ -287,5 +288,58 @@ def main():
     print("total fixture bytes", sz)
 
 
+
+
+def gen_metrics_and_masks(R):
+    """ImageMetrics.calc_ssim / calc_psnr / evaluate_batch (static parts) and CrackDataset's mask rasterisation,
+    the latter by running the real dataset class on a throw-away folder with two tiny PNGs + VOC XML files."""
+    import tempfile
+    from PIL import Image
+    out = {}
+    pairs = []
+    for i in range(6):
+        a = synth.synth_input(f"metrics.a{i}", (3, 32, 32))
+        b = a + 0.2 * synth.synth_input(f"metrics.b{i}", (3, 32, 32))
+        if i % 2 == 1:                      # already in [0, 1]: no rescale branch
+            a, b = (a.clamp(-1, 1) + 1) / 2, (b.clamp(-1, 1) + 1) / 2
+        if i == 4:
+            b = (b.clamp(-1, 1) + 1) / 2    # mixed ranges: only img1 is rescaled
+        pairs.append((a, b))
+    out["ssim"] = np.array([R.ImageMetrics.calc_ssim(a, b) for a, b in pairs], dtype=np.float64)
+    out["psnr"] = np.array([R.ImageMetrics.calc_psnr(a, b) for a, b in pairs], dtype=np.float64)
+    im = R.ImageMetrics.__new__(R.ImageMetrics)       # __init__ wants the pretrained InceptionV3 (remote fetch)
+    real = torch.stack([p[0] for p in pairs[:4]])
+    gen = torch.stack([p[1] for p in pairs[:4]])
+    ev = im.evaluate_batch(real, gen)
+    out["eval.ssim"], out["eval.psnr"] = np.float64(ev["ssim"]), np.float64(ev["psnr"])
+    # masks
+    boxes = [(13, 7, 57, 40, 100, 80), (0, 0, 300, 200, 300, 200), (5, 150, 25, 199, 64, 200), (33, 21, 34, 22, 67, 45)]
+    old = R.Cfg.IMG_SIZE
+    try:
+        for S in (64, 256):
+            R.Cfg.IMG_SIZE = S
+            with tempfile.TemporaryDirectory() as d:
+                os.makedirs(os.path.join(d, "images", "crack"))
+                os.makedirs(os.path.join(d, "annotations"))
+                for j, (x0, y0, x1, y1, w, h) in enumerate(boxes):
+                    Image.new("RGB", (w, h)).save(os.path.join(d, "images", "crack", f"im{j}.png"))
+                    with open(os.path.join(d, "annotations", f"im{j}.xml"), "w") as f:
+                        f.write(f"<annotation><size><width>{w}</width><height>{h}</height></size><object><bndbox>"
+                                f"<xmin>{x0}</xmin><ymin>{y0}</ymin><xmax>{x1}</xmax><ymax>{y1}</ymax></bndbox></object></annotation>")
+                ds = R.CrackDataset(d, transform=None)
+                order = {os.path.basename(s[0]): k for k, s in enumerate(ds.samples)}
+                for j in range(len(boxes)):
+                    _, label, mask = ds[order[f"im{j}.png"]]
+                    out[f"mask.S{S}.{j}"] = mask.numpy()
+    finally:
+        R.Cfg.IMG_SIZE = old
+    out["boxes"] = np.array(boxes)
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), **out)
+    print("metrics", out["ssim"], out["psnr"])
+
+
 if __name__ == "__main__":
-    main()
+    if os.environ.get("DM_GOLDEN_ONLY") == "metrics":
+        gen_metrics_and_masks(_refload.load("new_scripy"))
+    else:
+        main()
