@@ -424,7 +424,171 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvP p) {
     conv_epilogue<T, BN>(p, acc, smem, tid, wm, wn, fr, fg, mb, m0, n0);
 }
 
-int g_variant = 2;    // 1 = register staging, 2..4 = LDS-DMA with that many ring stages (2 workgroups/CU at 2)
+// =================================================================================================
+// v5: halo-resident 3x3 stride-1 kernel (bf16)
+// =================================================================================================
+// The gather kernels above re-fetch every input pixel once per tap: a 128x128 tile pulls 32 KiB from L2
+// into LDS per k-step, and the L2->LDS fill rate of a CU (~70 GB/s, MI355X_MICROARCH.md "Indexed rows:
+// gather into LDS"), not the MFMA, then bounds the 64x64 / 32x32 / 16x16 layers at < 50 % of peak.  Here a
+// 512-thread workgroup owns 256 output pixels = TH full image rows (W == TW in {64, 32, 16}) x 128 output
+// channels and keeps the INPUT HALO of one 64-channel chunk — (TH+2) x (TW+2) pixels x 128 B — resident
+// in LDS: all 9 taps are MFMA'd out of it through shifted fragment addresses, only the weights stream
+// (16 KiB per k-step, 3-stage ring).  L2->LDS bytes per k-step drop from 2 x 32 KiB (two 128x128
+// workgroups) to ~21.6 KiB for the same MFMA work.
+//   * halo image: row hp = hy*HS + hx (HS = TW+8, a multiple of 8), 128 B per row, 16-B slot v stored at
+//     v ^ (hp & 7).  As HS % 8 == 0 a tap shift (ky, kx) changes hp & 7 only through kx: the fragment
+//     addresses are 3 (kx) x 2 (sub-step) x 4 (pixel group) precomputed VGPRs plus an immediate.
+//   * staging: `buffer_load_dwordx4 ... lds` with a per-lane 32-bit offset that never changes (pixel /
+//     weight-row offset, or 0x80000000 = out of range -> the DMA writes zeros: image border, n >= N) and a
+//     scalar offset per k-step (channel chunk / tap).  No per-step address VALU.
+//   * the 9 taps are unrolled: ring stage = tap % 3, the next chunk's halo (<= 54 pieces of 8 px) is
+//     fetched one piece per wave per tap during taps 0..6 into the other halo buffer, all waits are
+//     compile-time `s_waitcnt vmcnt(N)` + one raw s_barrier per k-step.
+//   * 8 waves = 4 (pixel rows of 64) x 2 (64 channels): the wave tile, accumulator layout and epilogue are
+//     those of the 128x128 kernels (each half of the tile emits its own 128-row statistics partial).
+typedef __attribute__((address_space(3))) void* lds_dst;
+
+constexpr int HALO_PIECES = 54;                       // 1-KiB pieces per halo buffer (TW=64: 6x72/8, TW=16: 18x24/8)
+constexpr int HALO_BYTES = HALO_PIECES * 1024;
+constexpr int WSTAGE = 128 * ROWB;                    // one weight stage: 128 rows (n) x 128 B
+constexpr int HALO_LDS = 2 * HALO_BYTES + 3 * WSTAGE; // 159,744 B
+constexpr unsigned OOB = 0x80000000u;
+constexpr int SRD_FLAGS = 0x00020000;
+
+template <int TW>
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
+    constexpr int TH = 256 / TW, HS = TW + 8, HR = TH + 2, NP = HR * HS / 8;
+    static_assert(NP <= HALO_PIECES, "halo does not fit");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [halo 0][halo 1][w 0][w 1][w 2]
+    char* const sW = smem + 2 * HALO_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm4 = wave & 3, wn = wave >> 2;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nb_n = (p.N + 127) >> 7;
+    const int bid = remap_xcd(blockIdx.x, gridDim.x);
+    const int mb = bid / nb_n, nb = bid - mb * nb_n;
+    const int m0 = mb * 256, n0 = nb * 128;
+    const int C = p.C1 + p.C2;
+    const int nchunks = C >> 6;
+    const int tiles_img = (p.Hi * TW) >> 8;
+    const int b = mb / tiles_img, y0 = (mb - b * tiles_img) * TH;
+
+    const int pix_img = p.B * p.Hi * TW;
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.N * p.ldw * 2, SRD_FLAGS);
+
+    // ---- per-lane constants (nothing below changes inside the loop) ----
+    const int lrow = lane >> 3;
+    const int slotb = ((lane & 7) ^ lrow) << 4;          // byte offset of the logical vector this lane fetches
+    unsigned hv1[7], hv2[7];                               // halo pieces wave + 8 i: byte offset of the pixel in source 1 / 2
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int q = min(wave + 8 * i, NP - 1);           // surplus pieces re-fetch the last one (same bytes, same place)
+        const int hp = q * 8 + lrow;
+        const int hy = hp / HS, hx = hp - hy * HS;
+        const int y = y0 + hy - 1, x = hx - 1;
+        const bool ok = (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)TW;
+        const int pix = (b * p.Hi + y) * TW + x;
+        hv1[i] = ok ? (unsigned)(pix * p.C1 * 2 + slotb) : OOB;
+        hv2[i] = ok ? (unsigned)(pix * p.C2 * 2 + slotb) : OOB;
+    }
+    unsigned wv[2];                                        // weight pieces 2 wave + j: 8 rows (n) x 128 B
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + (wave * 2 + j) * 8 + lrow;
+        wv[j] = n < p.N ? (unsigned)(n * p.ldw * 2 + slotb) : OOB;
+    }
+    int hoff[3][2][4];                                     // pixel-operand fragment addresses in the current halo buffer
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int g = wm4 * 4 + mt;
+        const int ly = g / (TW / 16), lx0 = (g - ly * (TW / 16)) * 16;
+        const int base = (ly * HS + lx0 + fr) * ROWB;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) hoff[kx][sub][mt] = base + (((sub * 4 + fg) ^ ((fr + kx) & 7)) << 4);
+    }
+    int woff[2][4];                                        // weight-operand fragment addresses within a stage
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) woff[sub][nt] = lds_off(wn * 64 + nt * 16 + fr, sub * 4 + fg);
+
+    auto issue_w = [&](int tap, int chunk, int stage) {    // weights of k-step (chunk, tap) -> ring stage
+        const bool live = chunk < nchunks;
+        const int soff = (tap * C + (chunk << 6)) * 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_dst)(sW + stage * WSTAGE + (wave * 2 + j) * 1024), 16, live ? wv[j] : OOB,
+                                                     soff, 0, 0);
+    };
+    auto issue_h = [&](int i, int chunk, int buf) {        // halo piece wave + 8 i of `chunk` -> halo buffer
+        const bool live = chunk < nchunks;
+        const int c0 = chunk << 6;
+        const bool first = c0 < p.C1;
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? p.in1 : p.in2), 0,
+                                                                           pix_img * (first ? p.C1 : p.C2) * 2, SRD_FLAGS);
+        const unsigned v = first ? hv1[i] : hv2[i];
+        const int q = min(wave + 8 * i, NP - 1);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_dst)(smem + buf * HALO_BYTES + q * 1024), 16, live ? v : OOB,
+                                                 (first ? c0 : c0 - p.C1) * 2, 0, 0);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int i = 0; i < 7; ++i) issue_h(i, 0, 0);
+    issue_w(0, 0, 0);
+    issue_w(1, 0, 1);
+    int hdelta = HALO_BYTES;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int nbuf = (chunk + 1) & 1;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // everything older than the previous step's group (2 weight pieces + its halo piece) has landed
+            if (tap >= 1 && tap <= 7) wait_vmcnt<3>();
+            else wait_vmcnt<2>();
+            __builtin_amdgcn_s_barrier();
+            const int t2 = (tap + 2) % 9;
+            issue_w(t2, chunk + (tap + 2 >= 9 ? 1 : 0), t2 % 3);
+            if (tap < 7) issue_h(tap, chunk + 1, nbuf);
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const char* sWs = sW + (tap % 3) * WSTAGE;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                u32x4 fb[4], fa[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) fb[mt] = *(const u32x4*)(smem + hoff[kx][sub][mt] + (ky * HS + kx) * ROWB);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) fa[nt] = *(const u32x4*)(sWs + woff[sub][nt]);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) Mma<bf16>::run(fa[nt], fb[mt], acc[nt][mt]);
+            }
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) hoff[kx][sub][mt] += hdelta;
+        hdelta = -hdelta;
+    }
+    wait_vmcnt<0>();                     // the surplus (out-of-range) pieces of the last steps
+    __syncthreads();                     // the epilogue reuses the LDS for the statistics fold
+    const int half = wm4 >> 1;
+    const int tidh = (((wave & 1) + 2 * wn) << 6) + lane;
+    conv_epilogue<bf16, 128>(p, acc, smem + half * 4096, tidh, wm4 & 1, wn, fr, fg, mb * 2 + half, m0 + half * 128, n0);
+}
+
+int g_variant = 2;    // 1 = register staging, 2..4 = LDS-DMA with that many ring stages (2 workgroups/CU at 2), 5 = 2 + halo kernel
 
 template <typename T, int BN, int NS>
 int launch2(const ConvP& p, int64_t grid, hipStream_t st) {
@@ -451,8 +615,40 @@ int launch_bn(const ConvP& p, int64_t grid, int variant, hipStream_t st) {
     return rc;
 }
 
+template <int TW>
+int launch_halo(const ConvP& p, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
+        if (e != hipSuccess) { dm_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", HALO_LDS, hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    const int64_t grid = (int64_t)(p.M / 256) * cdiv(p.N, 128);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<TW>), dim3((unsigned)grid), dim3(512), HALO_LDS, st, p);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+// 3x3, stride 1, pad 1, whole image rows of 16/32/64 pixels, 64-channel chunks, byte offsets below 2^31
+bool halo_eligible(const ConvP& p) {
+    if (p.T != 9 || p.KW != 3 || p.ty != 1 || p.tx != 1 || p.sy != 1 || p.sx != 1 || p.oy0 != -1 || p.ox0 != -1) return false;
+    if (p.Hq != p.Hi || p.Wq != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi || p.osy != 1 || p.osx != 1 || p.ooy != 0 || p.oox != 0) return false;
+    if (p.Wi != 16 && p.Wi != 32 && p.Wi != 64) return false;
+    if ((p.Hi * p.Wi) % 256 != 0 || p.C1 % 64 != 0 || p.C2 % 64 != 0) return false;
+    const int64_t pix = (int64_t)p.B * p.Hi * p.Wi;
+    const int64_t cmax = p.C1 > p.C2 ? p.C1 : p.C2;
+    return pix * cmax * 2 < (1ll << 31) && (int64_t)p.N * p.ldw * 2 < (1ll << 31);
+}
+
 template <typename T>
 int launch_conv(const ConvP& p, bool small_offsets, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        if (g_variant == 5 && halo_eligible(p)) {
+            if (p.Wi == 64) return launch_halo<64>(p, st);
+            if (p.Wi == 32) return launch_halo<32>(p, st);
+            return launch_halo<16>(p, st);
+        }
+    }
     const int mblocks = cdiv(p.M, BM);
     int bn = 128;
     if (p.N <= 32) bn = 32;
@@ -472,7 +668,7 @@ int launch_conv(const ConvP& p, bool small_offsets, hipStream_t st) {
 }  // namespace
 
 extern "C" int dm_set_conv_variant(int variant) {
-    DM_CHECK_ARG(variant >= 1 && variant <= 4, "dm_set_conv_variant: 1 (register staging) or 2..4 (LDS-DMA ring stages)");
+    DM_CHECK_ARG(variant >= 1 && variant <= 5, "dm_set_conv_variant: 1 (register staging), 2..4 (LDS-DMA ring stages) or 5 (2 + halo-resident 3x3)");
     g_variant = variant;
     return DM_OK;
 }

@@ -104,6 +104,83 @@ def test_wgrad_bf16_exact_integers():
     assert torch.equal(conv.bias.grad.cpu(), g.sum((0, 2, 3)))
 
 
+@pytest.fixture
+def halo_variant():
+    """Route eligible 3x3 convolutions through the halo-resident kernel for the duration of a test."""
+    from diffusionmodel_amd import _lib
+    lib = _lib.load()
+    assert lib.dm_set_conv_variant(5) == 0
+    yield
+    assert lib.dm_set_conv_variant(int(__import__("os").environ.get("DM_CONV_VARIANT", "0")) or _lib.DEFAULT_CONV_VARIANT) == 0
+
+
+HALO_CASES = [
+    # B, C1, C2, Cout, H (= W)
+    (2, 64, 0, 128, 16),     # one chunk, one n-tile, tile = whole image
+    (1, 128, 0, 64, 32),     # two chunks, N < tile, 4 tiles per image (interior halo rows come from neighbours)
+    (1, 64, 0, 192, 64),     # two n-tiles, the second half empty; 16 tiles per image
+    (2, 64, 128, 64, 16),    # concatenated sources with different channel counts
+    (3, 192, 0, 136, 32),    # three chunks, ragged N, odd batch
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv_halo_kernel_exact_integers(case, halo_variant):
+    """Small-integer bf16 data: every product and partial sum is exact, so the halo kernel (chunk-major
+    k order, shifted fragment reads, zero-filling DMA) must reproduce F.conv2d bit for bit — forward and,
+    through the same kernel with transposed weights, the input gradient."""
+    o = ops()
+    B, C1, C2, Co, H = case
+    g = torch.Generator().manual_seed(C1 + Co + H)
+    ri = lambda *s: torch.randint(-1, 2, s, generator=g).float()
+    x1, x2 = ri(B, C1, H, H), (ri(B, C2, H, H) if C2 else None)
+    w, b, probe = ri(Co, C1 + C2, 3, 3), ri(Co), ri(B, Co, H, H)
+    keep = (torch.rand(Co, C1 + C2, 3, 3, generator=g) < 0.25).float()       # sparse weights keep |y| < 256 (exact in bf16)
+    w = w * keep
+    r1 = x1.clone().requires_grad_(True)
+    r2 = x2.clone().requires_grad_(True) if C2 else None
+    yr = F.conv2d(torch.cat((r1, r2), 1) if C2 else r1, w, b, padding=1)
+    assert yr.abs().max() < 256
+    (yr * probe).sum().backward()
+    conv = Holder(w, b)
+    d1 = nhwc(x1, torch.bfloat16).requires_grad_(True)
+    d2 = nhwc(x2, torch.bfloat16).requires_grad_(True) if C2 else None
+    y = o.conv_bn_act(d1, d2, conv, None, o.ConvSpec(3, 3, 1, 1))
+    assert torch.equal(nchw(y), yr.detach())
+    (y.float() * nhwc(probe)).sum().backward()
+    assert torch.equal(nchw(d1.grad), r1.grad)
+    if C2:
+        assert torch.equal(nchw(d2.grad), r2.grad)
+
+
+def test_conv_halo_kernel_bn_statistics(halo_variant):
+    """Train-mode BatchNorm behind the halo kernel: the two 128-row statistics partials a 256-pixel tile emits."""
+    o = ops()
+    B, Ci, Co, H = 2, 64, 128, 32
+    x = torch.randn(B, Ci, H, H).bfloat16().float()
+    conv_r = torch.nn.Conv2d(Ci, Co, 3, 1, 1)
+    with torch.no_grad():
+        conv_r.weight.copy_(conv_r.weight.bfloat16().float())
+    bn_r, bn_d = torch.nn.BatchNorm2d(Co), torch.nn.BatchNorm2d(Co).to(DEV)
+    with torch.no_grad():
+        bn_r.weight.uniform_(0.5, 1.5); bn_r.bias.uniform_(-0.3, 0.3)
+    bn_d.load_state_dict(bn_r.state_dict())
+    conv_d = Holder(conv_r.weight.detach().clone(), conv_r.bias.detach().clone())
+    xr = x.clone().requires_grad_(True)
+    yr = F.gelu(bn_r(conv_r(xr)))
+    probe = torch.randn_like(yr)
+    (yr * probe).sum().backward()
+    spec = o.ConvSpec(3, 3, 1, 1, o.ACT_GELU, bn_d)
+    xd = nhwc(x, torch.bfloat16).requires_grad_(True)
+    y = o.conv_bn_act(xd, None, conv_d, bn_d, spec)
+    assert rel_err(nchw(y), yr.detach()) < 4e-2
+    assert rel_err(bn_d.running_mean.cpu(), bn_r.running_mean) < 1e-2
+    assert rel_err(bn_d.running_var.cpu(), bn_r.running_var) < 1e-2
+    (y.float() * nhwc(probe)).sum().backward()
+    assert rel_err(nchw(xd.grad), xr.grad) < 0.16
+    assert rel_err(conv_d.weight.grad.cpu(), conv_r.weight.grad) < 0.16
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_concat_and_stem_pad_and_nchw_out(dtype):
     o = ops()
