@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=8)
     ap.add_argument("--cpu-iters", dest="cpu_iters", type=int, default=2)
     ap.add_argument("--buckets", type=int, default=4)
+    ap.add_argument("--shape-table", dest="shape_table", default="", help="write per-shape MFMA launch statistics to this file")
     ap.add_argument("--force-dp", dest="force_dp", action="store_true",
                     help="run the RCCL gradient all-reduce path even with one rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
@@ -164,11 +165,19 @@ def main():
 
     # ---- roofline of the dominant kernel family (implicit-GEMM conv fwd/dgrad + wgrad) from the events
     fl = {"conv_igemm": [0.0, 0.0, 0], "conv_wgrad": [0.0, 0.0, 0]}
-    for (kind, flops, e0, e1) in prof:
+    shapes = {}
+    for (kind, flops, e0, e1, shape) in prof:
+        sec = e0.elapsed_time(e1) * 1e-3
         fl.setdefault(kind, [0.0, 0.0, 0])
         fl[kind][0] += flops
-        fl[kind][1] += e0.elapsed_time(e1) * 1e-3
+        fl[kind][1] += sec
         fl[kind][2] += 1
+        sh = shapes.setdefault((kind, shape), [0.0, 0.0, 0])
+        sh[0] += flops; sh[1] += sec; sh[2] += 1
+    if args.shape_table and rank == 0:     # per-shape time / rate of the MFMA launches (tuning aid)
+        with open(args.shape_table, "w") as f:
+            for (kind, shape), (flo, sec, n) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{sec / args.steps * 1e3:8.3f} ms/step {n / args.steps:5.1f}x {sec / n * 1e6:8.1f} us {flo / sec / 1e12:8.1f} TF/s  {kind:11s} {shape}\n")
     if dtype != torch.bfloat16:
         fl["conv_igemm"], fl["conv_wgrad"] = fl.get("igemm_f32", [0.0, 0.0, 0]), fl.get("wgrad_f32", [0.0, 0.0, 0])
     dom = "conv_igemm"

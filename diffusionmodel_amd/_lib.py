@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdm_amd.so")
-DEFAULT_CONV_VARIANT = 2      # what libdm_amd.so starts with (igemm.hip g_variant); DM_CONV_VARIANT overrides
+DEFAULT_CONV_VARIANT = 5      # what libdm_amd.so starts with (igemm.hip g_variant); DM_CONV_VARIANT overrides
 
 DM_F32, DM_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3

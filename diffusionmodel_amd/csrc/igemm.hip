@@ -455,7 +455,7 @@ constexpr int HALO_LDS = 2 * HALO_BYTES + 3 * WSTAGE; // 159,744 B
 constexpr unsigned OOB = 0x80000000u;
 constexpr int SRD_FLAGS = 0x00020000;
 
-template <int TW>
+template <int TW, bool FLIP>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
     constexpr int TH = 256 / TW, HS = TW + 8, HR = TH + 2, NP = HR * HS / 8;
     static_assert(NP <= HALO_PIECES, "halo does not fit");
@@ -547,39 +547,41 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
     issue_w(0, 0, 0);
     issue_w(1, 0, 1);
     int hdelta = HALO_BYTES;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int nbuf = (chunk + 1) & 1;
+    {
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int nbuf = (chunk + 1) & 1;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            // everything older than the previous step's group (2 weight pieces + its halo piece) has landed
-            if (tap >= 1 && tap <= 7) wait_vmcnt<3>();
-            else wait_vmcnt<2>();
-            __builtin_amdgcn_s_barrier();
-            const int t2 = (tap + 2) % 9;
-            issue_w(t2, chunk + (tap + 2 >= 9 ? 1 : 0), t2 % 3);
-            if (tap < 7) issue_h(tap, chunk + 1, nbuf);
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const char* sWs = sW + (tap % 3) * WSTAGE;
+            for (int tap = 0; tap < 9; ++tap) {
+                // everything older than the previous step's group (2 weight pieces + its halo piece) has landed
+                if (tap >= 1 && tap <= 7) wait_vmcnt<3>();
+                else wait_vmcnt<2>();
+                __builtin_amdgcn_s_barrier();
+                const int t2 = (tap + 2) % 9;
+                issue_w(t2, chunk + (tap + 2 >= 9 ? 1 : 0), t2 % 3);
+                if (tap < 7) issue_h(tap, chunk + 1, nbuf);
+                const int ky = FLIP ? 2 - tap / 3 : tap / 3, kx = FLIP ? 2 - tap % 3 : tap % 3;   // halo offset of this tap
+                const char* sWs = sW + (tap % 3) * WSTAGE;
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                u32x4 fb[4], fa[4];
+                for (int sub = 0; sub < 2; ++sub) {
+                    u32x4 fb[4], fa[4];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) fb[mt] = *(const u32x4*)(smem + hoff[kx][sub][mt] + (ky * HS + kx) * ROWB);
+                    for (int mt = 0; mt < 4; ++mt) fb[mt] = *(const u32x4*)(smem + hoff[kx][sub][mt] + (ky * HS + kx) * ROWB);
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) fa[nt] = *(const u32x4*)(sWs + woff[sub][nt]);
+                    for (int nt = 0; nt < 4; ++nt) fa[nt] = *(const u32x4*)(sWs + woff[sub][nt]);
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) Mma<bf16>::run(fa[nt], fb[mt], acc[nt][mt]);
+                        for (int mt = 0; mt < 4; ++mt) Mma<bf16>::run(fa[nt], fb[mt], acc[nt][mt]);
+                }
             }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) hoff[kx][sub][mt] += hdelta;
+            hdelta = -hdelta;
         }
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) hoff[kx][sub][mt] += hdelta;
-        hdelta = -hdelta;
     }
     wait_vmcnt<0>();                     // the surplus (out-of-range) pieces of the last steps
     __syncthreads();                     // the epilogue reuses the LDS for the statistics fold
@@ -588,7 +590,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
     conv_epilogue<bf16, 128>(p, acc, smem + half * 4096, tidh, wm4 & 1, wn, fr, fg, mb * 2 + half, m0 + half * 128, n0);
 }
 
-int g_variant = 2;    // 1 = register staging, 2..4 = LDS-DMA with that many ring stages (2 workgroups/CU at 2), 5 = 2 + halo kernel
+int g_variant = 5;    // 1 = register staging, 2..4 = LDS-DMA with that many ring stages (2 workgroups/CU at 2),
+                      // 5 (default) = halo-resident kernel for eligible 3x3 layers, else LDS-DMA with 2 stages (4 on small grids)
 
 template <typename T, int BN, int NS>
 int launch2(const ConvP& p, int64_t grid, hipStream_t st) {
@@ -615,23 +618,25 @@ int launch_bn(const ConvP& p, int64_t grid, int variant, hipStream_t st) {
     return rc;
 }
 
-template <int TW>
+template <int TW, bool FLIP>
 int launch_halo(const ConvP& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<TW, FLIP>, hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
         if (e != hipSuccess) { dm_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", HALO_LDS, hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
     const int64_t grid = (int64_t)(p.M / 256) * cdiv(p.N, 128);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<TW>), dim3((unsigned)grid), dim3(512), HALO_LDS, st, p);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<TW, FLIP>), dim3((unsigned)grid), dim3(512), HALO_LDS, st, p);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
 
 // 3x3, stride 1, pad 1, whole image rows of 16/32/64 pixels, 64-channel chunks, byte offsets below 2^31
 bool halo_eligible(const ConvP& p) {
-    if (p.T != 9 || p.KW != 3 || p.ty != 1 || p.tx != 1 || p.sy != 1 || p.sx != 1 || p.oy0 != -1 || p.ox0 != -1) return false;
+    if (p.T != 9 || p.KW != 3 || p.sy != 1 || p.sx != 1) return false;
+    // forward taps (y-1+ky, x-1+kx), or the input-gradient's mirrored traversal (y+1-ky, x+1-kx)
+    if (!((p.ty == 1 && p.tx == 1 && p.oy0 == -1 && p.ox0 == -1) || (p.ty == -1 && p.tx == -1 && p.oy0 == 1 && p.ox0 == 1))) return false;
     if (p.Hq != p.Hi || p.Wq != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi || p.osy != 1 || p.osx != 1 || p.ooy != 0 || p.oox != 0) return false;
     if (p.Wi != 16 && p.Wi != 32 && p.Wi != 64) return false;
     if ((p.Hi * p.Wi) % 256 != 0 || p.C1 % 64 != 0 || p.C2 % 64 != 0) return false;
@@ -644,9 +649,10 @@ template <typename T>
 int launch_conv(const ConvP& p, bool small_offsets, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         if (g_variant == 5 && halo_eligible(p)) {
-            if (p.Wi == 64) return launch_halo<64>(p, st);
-            if (p.Wi == 32) return launch_halo<32>(p, st);
-            return launch_halo<16>(p, st);
+            const bool flip = p.ty < 0;
+            if (p.Wi == 64) return flip ? launch_halo<64, true>(p, st) : launch_halo<64, false>(p, st);
+            if (p.Wi == 32) return flip ? launch_halo<32, true>(p, st) : launch_halo<32, false>(p, st);
+            return flip ? launch_halo<16, true>(p, st) : launch_halo<16, false>(p, st);
         }
     }
     const int mblocks = cdiv(p.M, BM);
@@ -655,7 +661,9 @@ int launch_conv(const ConvP& p, bool small_offsets, hipStream_t st) {
     else if (p.N <= 64) bn = 64;
     else if ((int64_t)mblocks * cdiv(p.N, 128) < 256) bn = 64;  // small problems: more, smaller tiles
     const int64_t grid = (int64_t)mblocks * cdiv(p.N, bn);
-    const int variant = small_offsets ? g_variant : 1;
+    int variant = small_offsets ? g_variant : 1;
+    // fewer workgroups than CUs: nothing else hides the load latency, so run the ring 3 steps ahead instead of 1
+    if (variant == 5 && grid < 256) variant = 4;
     int rc;
     if (bn == 128) rc = launch_bn<T, 128>(p, grid, variant, st);
     else if (bn == 64) rc = launch_bn<T, 64>(p, grid, variant, st);

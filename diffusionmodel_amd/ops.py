@@ -21,7 +21,7 @@ from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, call, dt, ptr
 BN_EPS = 1e-5
 _EPOCH = [0]          # bumped by the fused optimiser: invalidates packed-weight caches
 _CACHE = {}
-PROFILE = None        # bench.py sets this to a list to collect (kind, flops, start_event, end_event)
+PROFILE = None        # bench.py sets this to a list to collect (kind, flops, start_event, end_event, shape)
 
 
 def bump_weight_epoch():
@@ -112,7 +112,8 @@ def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, s
         e0.record()
         call("dm_conv", C.byref(d))
         e1.record()
-        PROFILE.append(("conv_igemm" if dtype == torch.bfloat16 else "igemm_f32", 2.0 * B * Hq * Wq * N * T * (C1 + C2), e0, e1))
+        PROFILE.append(("conv_igemm" if dtype == torch.bfloat16 else "igemm_f32", 2.0 * B * Hq * Wq * N * T * (C1 + C2), e0, e1,
+                        f"B{B} {Hi}x{Wi} C{C1}+{C2} N{N} T{T} s{sy} t{ty} o{oy0} out{Ho}x{Wo}/{osy}"))
 
 
 def _wgrad_call(dy, in1, in2, dw, dbias, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0, Ho, Wo, N, ldy,
@@ -132,7 +133,8 @@ def _wgrad_call(dy, in1, in2, dw, dbias, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy
         e0.record()
         call("dm_conv_wgrad", C.byref(d))
         e1.record()
-        PROFILE.append(("conv_wgrad" if dtype == torch.bfloat16 else "wgrad_f32", 2.0 * B * Hq * Wq * N * T * (C1 + C2), e0, e1))
+        PROFILE.append(("conv_wgrad" if dtype == torch.bfloat16 else "wgrad_f32", 2.0 * B * Hq * Wq * N * T * (C1 + C2), e0, e1,
+                        f"B{B} {Hi}x{Wi} C{C1}+{C2} N{N} T{T} s{sy} q{Hq}x{Wq}"))
 
 
 class ConvSpec:

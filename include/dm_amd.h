@@ -57,7 +57,8 @@ typedef struct DmConv {
     int32_t N, ldw, ldc, coff;
 } DmConv;
 int dm_conv(const DmConv* d, dm_stream_t stream);
-/* tuning knob: staging pipeline of dm_conv — 1 = register staging, 2..4 = LDS-DMA ring with that many stages (default 2) */
+/* tuning knob: staging pipeline of dm_conv — 1 = register staging, 2..4 = LDS-DMA gather ring with that many stages,
+   5 (default) = halo-resident kernel for 3x3 stride-1 layers on 16/32/64-pixel rows with 64-channel multiples, gather ring otherwise */
 int dm_set_conv_variant(int variant);
 
 /* Weight gradient of the same gather convolution (fp32 atomics into dw, which the caller zeroes or

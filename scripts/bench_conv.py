@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--what", default="fwd,wgrad")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--zeros", action="store_true", help="all-zero operands: same cycles, higher sustained clock (DVFS check)")
+    ap.add_argument("--only", default="", help="substring filter on the shape name")
     args = ap.parse_args()
     if args.variant:
         os.environ["DM_CONV_VARIANT"] = str(args.variant)
@@ -42,8 +44,12 @@ def main():
     what = args.what.split(",")
     print(f"variant={args.variant or 'default'} dtype={args.dtype}")
     for name, B, H, Ci, Co, k, s in SHAPES:
+        if args.only and args.only not in name:
+            continue
         x = torch.randn(B, H, H, Ci, device=dev).to(dtype)
         w = (torch.randn(Co, k, k, Ci, device=dev) / (Ci * k * k) ** 0.5).to(dtype)
+        if args.zeros:
+            x.zero_(), w.zero_()
         p = (k - 1) // 2 if s == 1 else 1
         Ho = (H + 2 * p - k) // s + 1
         y = torch.empty(B, Ho, Ho, Co, device=dev, dtype=dtype)

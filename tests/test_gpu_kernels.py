@@ -104,12 +104,12 @@ def test_wgrad_bf16_exact_integers():
     assert torch.equal(conv.bias.grad.cpu(), g.sum((0, 2, 3)))
 
 
-@pytest.fixture
-def halo_variant():
-    """Route eligible 3x3 convolutions through the halo-resident kernel for the duration of a test."""
+@pytest.fixture(params=[5], ids=["halo"])
+def halo_variant(request):
+    """Route eligible 3x3 convolutions through the halo-resident kernel (either schedule) for the duration of a test."""
     from diffusionmodel_amd import _lib
     lib = _lib.load()
-    assert lib.dm_set_conv_variant(5) == 0
+    assert lib.dm_set_conv_variant(request.param) == 0
     yield
     assert lib.dm_set_conv_variant(int(__import__("os").environ.get("DM_CONV_VARIANT", "0")) or _lib.DEFAULT_CONV_VARIANT) == 0
 
