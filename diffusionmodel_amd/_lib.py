@@ -89,7 +89,7 @@ _PROTOS = {
     "dm_sumsq": [vp, i64, vp],
     "dm_adamw": [vp, vp, vp, vp, i64, vp, vp],
 }
-_NO_STREAM = {"dm_set_conv_variant": ([i32], i32), "dm_set_wgrad_variant": ([i32], i32), "dm_version": ([], i32), "dm_last_error": ([], C.c_char_p), "dm_colstat_blocks": ([i32], i32)}
+_NO_STREAM = {"dm_set_workspace": ([vp, i64], i32), "dm_set_conv_variant": ([i32], i32), "dm_set_wgrad_variant": ([i32], i32), "dm_version": ([], i32), "dm_last_error": ([], C.c_char_p), "dm_colstat_blocks": ([i32], i32)}
 
 EXPORTED = sorted(list(_PROTOS) + list(_NO_STREAM))
 
@@ -126,6 +126,21 @@ def load():
         if lib.dm_set_conv_variant(int(v)) != 0:
             raise DmError(lib.dm_last_error().decode())
     return lib
+
+
+_workspace = None
+WORKSPACE_BYTES = 160 << 20      # split partial sums of the weight-gradient kernels (dm_set_workspace)
+
+
+def ensure_workspace():
+    """Allocate the library's scratch buffer on the current device once and register it (dm_set_workspace)."""
+    global _workspace
+    if _workspace is None:
+        lib = load()
+        _workspace = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device="cuda")
+        if lib.dm_set_workspace(_workspace.data_ptr(), WORKSPACE_BYTES) != 0:
+            raise DmError(lib.dm_last_error().decode())
+    return _workspace
 
 
 def _stream():

@@ -375,8 +375,211 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgP p) {
     if (do_bias && n0 + tid < p.N) atomicAdd(p.dbias + n0 + tid, bias_acc);
 }
 
+// =================================================================================================
+// v3: halo-resident weight gradient of the 3x3 stride-1 layers (bf16)
+// =================================================================================================
+// The kernels above give every (n tile, tap, channel tile) its own workgroups, so the nine taps re-stage
+// the same dy and input rows nine times and the L2->LDS fill (32 KiB per 64-pixel step for 2.1 MFLOP)
+// bounds them.  Here a 512-thread workgroup owns the output block dw[128 n][9 taps][64 c] — 144 fp32
+// accumulators per lane — and walks over 128-pixel tiles (whole image rows): per tile it stages the
+// dy rows (32 KiB) and the INPUT HALO of one 64-channel chunk (<= 36 KiB) once and feeds all nine
+// taps from the halo through shifted transposed reads: 68 KiB of fill per 18.9 MFLOP.
+//   * both operands are read with ds_read_b64_tr_b16 (k = pixel is the row index of both images);
+//     lane group g takes pixels {4g..4g+3} and {16+4g..} of a 32-pixel k-step on both operands.
+//   * dy image: 256-B rows, 32-B chunk ch stored at ch ^ (row & 7); halo image: 128-B rows, chunk ch at
+//     ch ^ ((row >> 1) & 3): the 8 rows a 32-lane half touches fall on disjoint banks for ANY first row,
+//     so the tap shifts (whole rows: multiples of HS = TW + 8; columns: +0/1/2) stay conflict-free and
+//     every read address is one of 4 (dy) + 3 (halo, per kx) VGPRs plus an immediate.
+//   * staging: `buffer_load_dwordx4 ... lds`, swizzle on the source address, out-of-image lanes read
+//     zeros through the buffer range check; two stages, one barrier per 128-pixel tile (144 MFMAs/wave).
+//   * waves: 2 (64 n each) x 4 (16 of the chunk's 64 channels each, all 9 taps).
+//   * the pixel range is split over the workgroups that share an output block; the partials go to the
+//     workspace with plain stores (fp32 atomics issue at ~1 wave-instruction / 50 ns / CU: 56 us for a
+//     workgroup's 288 KiB) and wgrad_reduce_kernel adds them into dw.  dbias comes from the dy image.
+typedef __attribute__((address_space(3))) void* lds_dst3;
+constexpr unsigned WG_OOB = 0x80000000u;
+constexpr int WG_SRD = 0x00020000;
+constexpr int WGH_DY = 128 * 256;                 // dy image of a stage
+constexpr int WGH_STAGE = WGH_DY + 36 * 1024;     // + halo image (36 pieces of 8 pixels x 128 B at most)
+
+struct WgHP {
+    const char* dy; const char* in1; const char* in2; float* dw; float* dbias; float* ws;
+    int B, Hi, C1, C2, N, ldy, ldw;
+    int ntiles, nchunks, blocks, splits, tiles_per_split;
+};
+
+template <int TW>
+__global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
+    constexpr int R = 128 / TW, HS = TW + 8, HR = R + 2, XP = HR * HS / 8;    // 36 / 30 / 30 halo pieces
+    constexpr int XPW = (XP + 7) / 8;                                         // per wave
+    constexpr int HI = (TW == 16 ? HS : 16) * 128;                            // byte offset of the k-step's second 16 pixels in the halo
+    static_assert(XP <= 36, "halo does not fit");
+    extern __shared__ __attribute__((aligned(16))) char smem[];               // 2 stages
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wc = wave >> 1;
+    const int g = lane >> 4, il = lane & 15, q = il >> 2, pp = il & 3;
+
+    // workgroup -> (output block, pixel split); consecutive ids of one XCD share a pixel range
+    const int G = gridDim.x;
+    int idx = blockIdx.x;
+    if ((G & 7) == 0) idx = (idx & 7) * (G >> 3) + (idx >> 3);
+    const int block = idx % p.blocks, split = idx / p.blocks;
+    const int nbk = block / p.nchunks, chunk = block - nbk * p.nchunks;
+    const int n0 = nbk * 128, c0 = chunk * 64;
+    const int C = p.C1 + p.C2;
+    const bool first = c0 < p.C1;
+    const int Cs = first ? p.C1 : p.C2;
+    const int cin0 = first ? c0 : c0 - p.C1;
+    const int t_lo = split * p.tiles_per_split, t_hi = min(t_lo + p.tiles_per_split, p.ntiles);
+    const int tiles_img = (p.Hi * TW) >> 7;
+
+    const __amdgpu_buffer_rsrc_t rDY = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.ntiles * 128 * p.ldy * 2, WG_SRD);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? p.in1 : p.in2), 0, p.ntiles * 128 * Cs * 2, WG_SRD);
+
+    // ---- staging constants
+    unsigned dyv[4];                                   // dy pieces 4 wave + j: 4 rows x 256 B
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 4 + (lane >> 4), s = lane & 15;
+        const int lslot = ((((s >> 1) ^ (row & 7)) << 1) | (s & 1));
+        const int ncol = n0 + lslot * 8;
+        dyv[j] = ncol + 8 <= p.ldy ? (unsigned)((row * p.ldy + ncol) * 2) : WG_OOB;
+    }
+    int xrel[XPW], xflag[XPW], xslot[XPW];             // halo pieces wave + 8 i: 8 pixels x 128 B
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+        const int px = min(wave + 8 * i, XP - 1);
+        const int hp = px * 8 + (lane >> 3), s = lane & 7;
+        const int hy = hp / HS, hx = hp - hy * HS;
+        const int lslot = ((((s >> 1) ^ ((hp >> 1) & 3)) << 1) | (s & 1));
+        xrel[i] = (hy - 1) * TW + hx - 1;
+        xflag[i] = ((unsigned)(hx - 1) < (unsigned)TW ? 1 : 0) | (hy == 0 ? 2 : 0) | (hy == HR - 1 ? 4 : 0);
+        xslot[i] = lslot * 16 + cin0 * 2;
+    }
+    auto issue = [&](int stage, int tile) {
+        char* sA = smem + stage * WGH_STAGE;
+        char* sX = sA + WGH_DY;
+        const int soff = tile * 128 * p.ldy * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rDY, (lds_dst3)(sA + (wave * 4 + j) * 1024), 16, dyv[j], soff, 0, 0);
+        const int y0 = (tile % tiles_img) * R;
+        const int edge = (y0 == 0 ? 2 : 0) | (y0 + R == p.Hi ? 4 : 0);     // halo rows outside the image
+#pragma unroll
+        for (int i = 0; i < XPW; ++i) {
+            const bool ok = (xflag[i] & 1) && !(xflag[i] & edge);
+            const unsigned v = ok ? (unsigned)((tile * 128 + xrel[i]) * Cs * 2 + xslot[i]) : WG_OOB;
+            const int px = min(wave + 8 * i, XP - 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_dst3)(sX + px * 1024), 16, v, 0, 0, 0);
+        }
+    };
+
+    // ---- fragment read addresses
+    int addrA[4], addrB[3];
+    {
+        const int row = 4 * g + q;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) addrA[it] = row * 256 + (((wn * 4 + it) ^ (row & 7)) << 5) + 8 * pp;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) addrB[kx] = WGH_DY + (row + kx) * 128 + ((wc ^ (((row + kx) >> 1) & 3)) << 5) + 8 * pp;
+    }
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    auto tr_pair = [&](const char* a, int hi) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a));
+        const s16x4 h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a + hi));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], h[0], h[1], h[2], h[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    f32x4 acc[4][9];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bias_acc = 0.f;
+    const bool do_bias = p.dbias != nullptr && chunk == 0;
+    const int bcol = tid & 127, brow0 = (tid >> 7) * 32;
+
+    if (t_lo < t_hi) issue(0, t_lo);
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+        const int cur = (tile - t_lo) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // this tile has landed for every wave; the other stage is free again
+        if (tile + 1 < t_hi) issue(cur ^ 1, tile + 1);
+        const char* sS = smem + cur * WGH_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int koffA = ks * 32 * 256;
+            const int koffB = (TW == 64 ? (ks >> 1) * HS + (ks & 1) * 32 : TW == 32 ? ks * HS : 2 * ks * HS) * 128;
+            bf16x8 fa[4], fb[9];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) fa[it] = tr_pair(sS + addrA[it] + koffA, 16 * 256);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) fb[t] = tr_pair(sS + addrB[t % 3] + koffB + ((t / 3) * HS) * 128, HI);
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) acc[it][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[it], fb[t], acc[it][t], 0, 0, 0);
+        }
+        if (do_bias) {
+#pragma unroll 8
+            for (int r = brow0; r < brow0 + 32; ++r)
+                bias_acc += (float)*(const bf16*)(sS + r * 256 + (((bcol >> 4) ^ (r & 7)) << 5) + (bcol & 15) * 2);
+        }
+    }
+
+    // ---- flush: D[i = n][j = c] per tap; lane holds rows 4g..4g+3 (n), column il (c)
+    const int TC = 9 * C;
+    const bool direct = p.splits == 1;
+    float* dst = direct ? p.dw : p.ws + (size_t)split * p.N * TC;
+    const int ld = direct ? p.ldw : TC;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn * 64 + it * 16 + 4 * g + r;
+            if (n >= p.N) continue;
+            float* row = dst + (size_t)n * ld + c0 + wc * 16 + il;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (direct) row[t * C] += acc[it][t][r];      // sole owner of this element within the launch
+                else row[t * C] = acc[it][t][r];
+            }
+        }
+    if (do_bias && n0 + bcol < p.N) atomicAdd(p.dbias + n0 + bcol, bias_acc);
+}
+
+// dw[n][j] += sum over the pixel splits of ws[s][n][j]   (j < TC)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int N, int TC, int ldw, int splits) {
+    const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total4 = (int64_t)N * TC / 4;
+    if (i4 >= total4) return;
+    const int64_t e = i4 * 4;
+    const int n = (int)(e / TC), j = (int)(e - (int64_t)n * TC);
+    const f32x4* src = (const f32x4*)(ws + e);
+    const int64_t stride4 = (int64_t)N * TC / 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int k = 0; k < splits; ++k) s += src[k * stride4];
+    float* o = dw + (size_t)n * ldw + j;
+    if (((uintptr_t)o & 15) == 0) {
+        f32x4 v = *(f32x4*)o;
+        *(f32x4*)o = v + s;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] += s[r];
+    }
+}
+
+float* g_ws = nullptr;       // caller-owned scratch registered through dm_set_workspace
+int64_t g_ws_bytes = 0;
+int g_wgrad_halo = 1;
+
 int g_wgrad_variant = 2;
-int g_wgrad_blocks = 1024;   // workgroups the pixel split aims at (more splits = more parallelism but more fp32 atomic traffic)
+int g_wgrad_blocks = 1024;  // workgroups the pixel split aims at (more splits = more parallelism but more fp32 atomic traffic)
 
 template <typename T>
 int launch_wgrad(WgP& p, int splitk_req, bool v2_ok, hipStream_t st) {
@@ -417,11 +620,65 @@ int launch_wgrad(WgP& p, int splitk_req, bool v2_ok, hipStream_t st) {
 
 }  // namespace
 
+template <int TW>
+int launch_wgrad_halo(const WgHP& p, hipStream_t st) {
+    constexpr int bytes = 2 * WGH_STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_halo_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) { dm_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", bytes, hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad3x3_halo_kernel<TW>), dim3((unsigned)(p.blocks * p.splits)), dim3(512), bytes, st, p);
+    DM_LAUNCH_CHECK();
+    if (p.splits > 1) {
+        const int TC = 9 * (p.C1 + p.C2);
+        const int64_t total4 = (int64_t)p.N * TC / 4;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(total4, (int64_t)256)), dim3(256), 0, st, p.ws, p.dw, p.N, TC, p.ldw, p.splits);
+        DM_LAUNCH_CHECK();
+    }
+    return DM_OK;
+}
+
+// bf16 3x3 stride-1 pad-1 layer on whole 16/32/64-pixel rows, 64-channel chunks, identity dy mapping, 31-bit byte offsets.
+// Returns true (and fills hp) when the halo kernel can take the launch with the registered workspace.
+bool wgrad_halo_plan(const DmWgrad* d, int64_t M, WgHP& hp) {
+    if (!g_wgrad_halo || d->dtype != DM_BF16 || d->T != 9 || d->KW != 3 || d->sy != 1 || d->sx != 1) return false;
+    if (d->ty != 1 || d->tx != 1 || d->oy0 != -1 || d->ox0 != -1) return false;
+    if (d->Hq != d->Hi || d->Wq != d->Wi || d->Ho != d->Hq || d->Wo != d->Wq || d->osy != 1 || d->osx != 1 || d->ooy != 0 || d->oox != 0) return false;
+    if (d->Wi != 16 && d->Wi != 32 && d->Wi != 64) return false;
+    if ((d->Hi * d->Wi) % 128 != 0 || d->C1 % 64 != 0 || d->C2 % 64 != 0 || d->ldy % 8 != 0) return false;
+    const int64_t cmax = d->C1 > d->C2 ? d->C1 : d->C2;
+    if (M * cmax * 2 >= (1ll << 31) || M * d->ldy * 2 >= (1ll << 31)) return false;
+    if (((uintptr_t)d->dy & 15) || ((uintptr_t)d->in1 & 15) || ((uintptr_t)d->in2 & 15)) return false;
+    const int C = d->C1 + d->C2;
+    hp.dy = (const char*)d->dy; hp.in1 = (const char*)d->in1; hp.in2 = (const char*)d->in2; hp.dw = d->dw; hp.dbias = d->dbias; hp.ws = g_ws;
+    hp.B = d->B; hp.Hi = d->Hi; hp.C1 = d->C1; hp.C2 = d->C2; hp.N = d->N; hp.ldy = d->ldy; hp.ldw = d->ldw;
+    hp.ntiles = (int)(M / 128);
+    hp.nchunks = C / 64;
+    hp.blocks = cdiv(d->N, 128) * hp.nchunks;
+    int splits = 256 / hp.blocks;
+    if (splits < 1) splits = 1;
+    if (splits > hp.ntiles) splits = hp.ntiles;
+    hp.tiles_per_split = cdiv(hp.ntiles, splits);
+    hp.splits = cdiv(hp.ntiles, hp.tiles_per_split);
+    if (hp.splits > 1 && (g_ws == nullptr || (int64_t)hp.splits * d->N * 9 * C * 4 > g_ws_bytes)) return false;
+    return true;
+}
+
+extern "C" int dm_set_workspace(void* ws, int64_t bytes) {
+    DM_CHECK_ARG((ws == nullptr) == (bytes == 0) && bytes >= 0 && ((uintptr_t)ws & 15) == 0, "dm_set_workspace: need a 16-byte aligned buffer and its size (or NULL, 0)");
+    g_ws = (float*)ws;
+    g_ws_bytes = bytes;
+    return DM_OK;
+}
+
 extern "C" int dm_set_wgrad_variant(int variant) {
     // variant >= 64 sets the workgroup target of the pixel split instead (tuning)
     if (variant >= 64) { g_wgrad_blocks = variant; return DM_OK; }
-    DM_CHECK_ARG(variant == 1 || variant == 2, "dm_set_wgrad_variant: 1 (register staging) or 2 (LDS-DMA)");
-    g_wgrad_variant = variant;
+    DM_CHECK_ARG(variant >= 1 && variant <= 3, "dm_set_wgrad_variant: 1 (register staging), 2 (LDS-DMA) or 3 (2 + halo-resident 3x3, default)");
+    g_wgrad_halo = variant == 3;
+    g_wgrad_variant = variant == 3 ? 2 : variant;
     return DM_OK;
 }
 
@@ -439,6 +696,12 @@ extern "C" int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream) {
     const int64_t M = (int64_t)d->B * d->Hq * d->Wq;
     DM_CHECK_ARG(M < (1ll << 31), "dm_conv_wgrad: M too large");
     DM_CHECK_ARG((int64_t)d->T * cdiv(d->C1 + d->C2, 128) < 65536, "dm_conv_wgrad: grid.y too large");
+    WgHP hp;
+    if (wgrad_halo_plan(d, M, hp)) {
+        if (d->Wi == 64) return launch_wgrad_halo<64>(hp, (hipStream_t)stream);
+        if (d->Wi == 32) return launch_wgrad_halo<32>(hp, (hipStream_t)stream);
+        return launch_wgrad_halo<16>(hp, (hipStream_t)stream);
+    }
     WgP p;
     p.dy = (const char*)d->dy; p.in1 = (const char*)d->in1; p.in2 = (const char*)d->in2; p.dw = d->dw; p.dbias = d->dbias;
     p.B = d->B; p.Hi = d->Hi; p.Wi = d->Wi; p.C1 = d->C1; p.C2 = d->C2; p.Hq = d->Hq; p.Wq = d->Wq; p.sy = d->sy; p.sx = d->sx;

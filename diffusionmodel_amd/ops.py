@@ -118,6 +118,7 @@ def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, s
 
 def _wgrad_call(dy, in1, in2, dw, dbias, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0, Ho, Wo, N, ldy,
                 ldw, osy=1, osx=1, ooy=0, oox=0, splitk=0):
+    L.ensure_workspace()          # split partial sums of the halo-resident weight-gradient kernel
     d = L.DmWgrad()
     d.dy, d.in1, d.in2, d.dw, d.dbias = ptr(dy), ptr(in1), ptr(in2), ptr(dw), ptr(dbias)
     d.dtype = dt(dtype)

@@ -75,7 +75,12 @@ typedef struct DmWgrad {
     int32_t N, ldy, ldw, splitk;
 } DmWgrad;
 int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream);
-int dm_set_wgrad_variant(int variant);   /* tuning knob: 1 = register staging, 2 = LDS-DMA (default) */
+/* tuning knob: 1 = register staging, 2 = LDS-DMA, 3 (default) = 2 + the halo-resident kernel for 3x3 stride-1 layers
+   (needs dm_set_workspace when the pixel range is split over workgroups; falls back to 2 without it) */
+int dm_set_wgrad_variant(int variant);
+/* Caller-owned device scratch (16-byte aligned) the MFMA kernels may use for split partial sums; it must outlive every
+   launch that follows.  One stream at a time: launches that use it are ordered by the stream they are issued on. */
+int dm_set_workspace(void* ws, int64_t bytes);
 
 /* Weight repacks. src is the fp32 master in physical layout [N][T][C] (= torch channels_last of OIHW).
  *  dm_pack_w:   dst[n][t][cp]      = c < C ? src[n][t][c] : 0          (cast + channel pad), dst dtype

@@ -126,9 +126,9 @@ HALO_CASES = [
 
 @pytest.mark.parametrize("case", HALO_CASES)
 def test_conv_halo_kernel_exact_integers(case, halo_variant):
-    """Small-integer bf16 data: every product and partial sum is exact, so the halo kernel (chunk-major
-    k order, shifted fragment reads, zero-filling DMA) must reproduce F.conv2d bit for bit — forward and,
-    through the same kernel with transposed weights, the input gradient."""
+    """Small-integer bf16 data: every product and partial sum is exact, so the halo kernels (chunk-major
+    k order, shifted fragment reads, zero-filling DMA) must reproduce F.conv2d bit for bit — forward,
+    the input gradient (same kernel, transposed weights, mirrored taps) and the weight gradient."""
     o = ops()
     B, C1, C2, Co, H = case
     g = torch.Generator().manual_seed(C1 + Co + H)
@@ -139,7 +139,8 @@ def test_conv_halo_kernel_exact_integers(case, halo_variant):
     w = w * keep
     r1 = x1.clone().requires_grad_(True)
     r2 = x2.clone().requires_grad_(True) if C2 else None
-    yr = F.conv2d(torch.cat((r1, r2), 1) if C2 else r1, w, b, padding=1)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(torch.cat((r1, r2), 1) if C2 else r1, wr, br, padding=1)
     assert yr.abs().max() < 256
     (yr * probe).sum().backward()
     conv = Holder(w, b)
@@ -151,6 +152,9 @@ def test_conv_halo_kernel_exact_integers(case, halo_variant):
     assert torch.equal(nchw(d1.grad), r1.grad)
     if C2:
         assert torch.equal(nchw(d2.grad), r2.grad)
+    # weight / bias gradient (halo-resident wgrad kernel + split reduction): integer sums, exact in fp32
+    assert torch.equal(conv.weight.grad.cpu(), wr.grad)
+    assert torch.equal(conv.bias.grad.cpu(), br.grad)
 
 
 def test_conv_halo_kernel_bn_statistics(halo_variant):
