@@ -411,7 +411,6 @@ struct WgHP {
 template <int TW>
 __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
     constexpr int R = 128 / TW, HS = TW + 8, HR = R + 2, XP = HR * HS / 8;    // 36 / 30 / 30 halo pieces
-    constexpr int XPW = (XP + 7) / 8;                                         // per wave
     constexpr int HI = (TW == 16 ? HS : 16) * 128;                            // byte offset of the k-step's second 16 pixels in the halo
     static_assert(XP <= 36, "halo does not fit");
     extern __shared__ __attribute__((aligned(16))) char smem[];               // 2 stages
@@ -438,25 +437,35 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
     const __amdgpu_buffer_rsrc_t rDY = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.ntiles * 128 * p.ldy * 2, WG_SRD);
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? p.in1 : p.in2), 0, p.ntiles * 128 * Cs * 2, WG_SRD);
 
-    // ---- staging constants
-    unsigned dyv[4];                                   // dy pieces 4 wave + j: 4 rows x 256 B
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = (wave * 4 + j) * 4 + (lane >> 4), s = lane & 15;
+    // ---- staging: every per-lane quantity is ONE register per image; the piece index moves through scalar offsets
+    // dy pieces 8 j + wave (4 rows x 256 B each): row & 7 does not depend on j, so neither does the lane's source column
+    unsigned dyv;
+    {
+        const int row = wave * 4 + (lane >> 4), s = lane & 15;
         const int lslot = ((((s >> 1) ^ (row & 7)) << 1) | (s & 1));
         const int ncol = n0 + lslot * 8;
-        dyv[j] = ncol + 8 <= p.ldy ? (unsigned)((row * p.ldy + ncol) * 2) : WG_OOB;
+        dyv = ncol + 8 <= p.ldy ? (unsigned)((row * p.ldy + ncol) * 2) : WG_OOB;
     }
-    int xrel[XPW], xflag[XPW], xslot[XPW];             // halo pieces wave + 8 i: 8 pixels x 128 B
-#pragma unroll
-    for (int i = 0; i < XPW; ++i) {
-        const int px = min(wave + 8 * i, XP - 1);
-        const int hp = px * 8 + (lane >> 3), s = lane & 7;
-        const int hy = hp / HS, hx = hp - hy * HS;
-        const int lslot = ((((s >> 1) ^ ((hp >> 1) & 3)) << 1) | (s & 1));
-        xrel[i] = (hy - 1) * TW + hx - 1;
-        xflag[i] = ((unsigned)(hx - 1) < (unsigned)TW ? 1 : 0) | (hy == 0 ? 2 : 0) | (hy == HR - 1 ? 4 : 0);
-        xslot[i] = lslot * 16 + cin0 * 2;
+    // halo pieces (8 pixels x 128 B): a wave takes one 8-pixel column strip of the halo and walks down its rows, so the
+    // lane's column, swizzle and x-validity are fixed and a row is a scalar step.  NC strips x HR rows:
+    //   TW=64: 9 x 4 — waves 0..7 take strips 0..7, waves 0..3 also row `wave` of strip 8;   TW=32: 5 x 6 — waves 0..4;
+    //   TW=16: 3 x 10 — waves 0..5 as 3 strips x 2 groups of 5 rows.
+    constexpr int NC = HS / 8, RG = TW == 16 ? 2 : 1, RPG = HR / RG;
+    const int strip = wave % (NC < 8 ? NC : 8), rgroup = wave / (NC < 8 ? NC : 8);
+    const bool halo_wave = rgroup < RG;
+    const int hy0 = rgroup * RPG;
+    int xv0, xv8 = 0;
+    bool xok0, xok8 = false;
+    {
+        const int hx = strip * 8 + (lane >> 3), s = lane & 7;
+        const int lslot = ((((s >> 1) ^ ((hx >> 1) & 3)) << 1) | (s & 1));       // HS % 8 == 0: the swizzle follows hx only
+        xv0 = ((hy0 - 1) * TW + hx - 1) * Cs * 2 + lslot * 16 + cin0 * 2;
+        xok0 = (unsigned)(hx - 1) < (unsigned)TW;
+        if constexpr (TW == 64) {
+            const int hx8 = 64 + (lane >> 3);
+            xv8 = ((wave - 1) * TW + hx8 - 1) * Cs * 2 + lslot * 16 + cin0 * 2;      // row `wave` of strip 8 (64 % 8 == 0: same lslot)
+            xok8 = hx8 - 1 < TW;
+        }
     }
     auto issue = [&](int stage, int tile) {
         char* sA = smem + stage * WGH_STAGE;
@@ -464,15 +473,25 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
         const int soff = tile * 128 * p.ldy * 2;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rDY, (lds_dst3)(sA + (wave * 4 + j) * 1024), 16, dyv[j], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rDY, (lds_dst3)(sA + (j * 8 + wave) * 1024), 16, dyv, soff + j * 32 * p.ldy * 2, 0, 0);
         const int y0 = (tile % tiles_img) * R;
-        const int edge = (y0 == 0 ? 2 : 0) | (y0 + R == p.Hi ? 4 : 0);     // halo rows outside the image
+        const bool top = y0 == 0, bottom = y0 + R == p.Hi;                 // halo rows outside the image
+        const int tbase = tile * 128 * Cs * 2;
+        if (halo_wave) {
 #pragma unroll
-        for (int i = 0; i < XPW; ++i) {
-            const bool ok = (xflag[i] & 1) && !(xflag[i] & edge);
-            const unsigned v = ok ? (unsigned)((tile * 128 + xrel[i]) * Cs * 2 + xslot[i]) : WG_OOB;
-            const int px = min(wave + 8 * i, XP - 1);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_dst3)(sX + px * 1024), 16, v, 0, 0, 0);
+            for (int i = 0; i < RPG; ++i) {
+                const int hy = hy0 + i;
+                const bool row_ok = !((hy == 0 && top) || (hy == HR - 1 && bottom));
+                const unsigned v = (xok0 && row_ok) ? (unsigned)(tbase + i * TW * Cs * 2 + xv0) : WG_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_dst3)(sX + (hy * NC + strip) * 1024), 16, v, 0, 0, 0);
+            }
+        }
+        if constexpr (TW == 64) {
+            if (wave < 4) {
+                const bool row_ok = !((wave == 0 && top) || (wave == HR - 1 && bottom));
+                const unsigned v = (xok8 && row_ok) ? (unsigned)(tbase + xv8) : WG_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_dst3)(sX + (wave * NC + 8) * 1024), 16, v, 0, 0, 0);
+            }
         }
     };
 
@@ -499,9 +518,12 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float bias_acc = 0.f;
-    const bool do_bias = p.dbias != nullptr && chunk == 0;
-    const int bcol = tid & 127, brow0 = (tid >> 7) * 32;
+    // dbias[n] = sum over pixels of dy, straight from the dy image.  Every chunk of an n tile stages the same dy rows,
+    // so the tiles are dealt round-robin over the chunks; a thread sums 4 columns x 8 rows of its tile.
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool want_bias = p.dbias != nullptr;
+    const int bcol = (tid & 31) * 4, brow = tid >> 5;
+    int bphase = t_lo % p.nchunks;
 
     if (t_lo < t_hi) issue(0, t_lo);
     for (int tile = t_lo; tile < t_hi; ++tile) {
@@ -523,55 +545,87 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
             for (int t = 0; t < 9; ++t)
 #pragma unroll
                 for (int it = 0; it < 4; ++it) acc[it][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[it], fb[t], acc[it][t], 0, 0, 0);
+            // keep the k-steps apart: merged / hoisted halo reads push the kernel past 256 VGPRs, and a scratch reload in the
+            // loop waits on vmcnt — i.e. on the next tile's DMA — which serialises staging and compute
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (do_bias) {
-#pragma unroll 8
-            for (int r = brow0; r < brow0 + 32; ++r)
-                bias_acc += (float)*(const bf16*)(sS + r * 256 + (((bcol >> 4) ^ (r & 7)) << 5) + (bcol & 15) * 2);
+        if (want_bias && bphase == chunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = brow + 16 * j;
+                const bf16x4 v = *(const bf16x4*)(sS + r * 256 + (((bcol >> 4) ^ (r & 7)) << 5) + (bcol & 15) * 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bsum[e] += (float)v[e];
+            }
         }
+        bphase = bphase + 1 == p.nchunks ? 0 : bphase + 1;
     }
 
     // ---- flush: D[i = n][j = c] per tap; lane holds rows 4g..4g+3 (n), column il (c)
-    const int TC = 9 * C;
-    const bool direct = p.splits == 1;
-    float* dst = direct ? p.dw : p.ws + (size_t)split * p.N * TC;
-    const int ld = direct ? p.ldw : TC;
+    if (p.splits == 1) {                         // sole owner of its dw elements within the launch
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
+        for (int it = 0; it < 4; ++it)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + wn * 64 + it * 16 + 4 * g + r;
-            if (n >= p.N) continue;
-            float* row = dst + (size_t)n * ld + c0 + wc * 16 + il;
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + it * 16 + 4 * g + r;
+                if (n >= p.N) continue;
+                float* row = p.dw + (size_t)n * p.ldw + c0 + wc * 16 + il;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                if (direct) row[t * C] += acc[it][t][r];      // sole owner of this element within the launch
-                else row[t * C] = acc[it][t][r];
+                for (int t = 0; t < 9; ++t) row[t * C] += acc[it][t][r];
             }
+    } else {                                     // register image as it stands: 1 KiB contiguous per wave-instruction
+        f32x4* dst = (f32x4*)p.ws + ((((size_t)split * p.blocks + block) * 8 + wave) * 36) * 64 + lane;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) dst[(it * 9 + t) * 64] = acc[it][t];
+    }
+    if (want_bias) {                             // fold the 16 row groups in LDS, then one value per column and workgroup
+        __syncthreads();
+        float* sb = (float*)smem;                // [16][128]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sb[brow * 128 + bcol + e] = bsum[e];
+        __syncthreads();
+        if (tid < 128) {
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v += sb[j * 128 + tid];
+            if (p.splits > 1) p.ws[(size_t)p.splits * p.blocks * (128 * 9 * 64) + ((size_t)split * p.blocks + block) * 128 + tid] = v;
+            else if (n0 + tid < p.N) atomicAdd(p.dbias + n0 + tid, v);
         }
-    if (do_bias && n0 + bcol < p.N) atomicAdd(p.dbias + n0 + bcol, bias_acc);
+    }
 }
 
-// dw[n][j] += sum over the pixel splits of ws[s][n][j]   (j < TC)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int N, int TC, int ldw, int splits) {
-    const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t total4 = (int64_t)N * TC / 4;
-    if (i4 >= total4) return;
-    const int64_t e = i4 * 4;
-    const int n = (int)(e / TC), j = (int)(e - (int64_t)n * TC);
-    const f32x4* src = (const f32x4*)(ws + e);
-    const int64_t stride4 = (int64_t)N * TC / 4;
+// dw += sum over the pixel splits of the register images in ws: slot e = ((block*8 + wave)*36 + it*9 + t)*64 + lane holds
+// rows n = 4g..4g+3 of the 16x16 tile (it, t) of that wave, column c = il
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restrict__ ws, float* __restrict__ dw, float* __restrict__ dbias, int N,
+                                                            int C, int nchunks, int blocks, int ldw, int splits) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int per_split = blocks * 8 * 36 * 64;
+    if (e >= per_split) {                        // trailing waves, one per n: dbias[n] += the per-workgroup column sums of dy
+        const int n = (e - per_split) >> 6, l = e & 63;
+        if (dbias == nullptr || n >= N) return;
+        const float* wb = (const float*)(ws + (size_t)splits * per_split);
+        float v = 0.f;
+        for (int i = l; i < splits * nchunks; i += 64) {
+            const int k = i / nchunks, ch = i - k * nchunks;
+            v += wb[((size_t)k * blocks + (n >> 7) * nchunks + ch) * 128 + (n & 127)];
+        }
+        v = wave_sum(v);
+        if (l == 0) dbias[n] += v;
+        return;
+    }
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-    for (int k = 0; k < splits; ++k) s += src[k * stride4];
-    float* o = dw + (size_t)n * ldw + j;
-    if (((uintptr_t)o & 15) == 0) {
-        f32x4 v = *(f32x4*)o;
-        *(f32x4*)o = v + s;
-    } else {
+    for (int k = 0; k < splits; ++k) s += ws[(size_t)k * per_split + e];
+    const int lane = e & 63, tile = (e >> 6) % 36, wave = (e / (64 * 36)) & 7, block = e / (64 * 36 * 8);
+    const int it = tile / 9, t = tile - it * 9;
+    const int nbk = block / nchunks, chunk = block - nbk * nchunks;
+    const int n = nbk * 128 + (wave & 1) * 64 + it * 16 + 4 * (lane >> 4);
+    float* o = dw + (size_t)n * ldw + t * C + chunk * 64 + (wave >> 1) * 16 + (lane & 15);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] += s[r];
-    }
+    for (int r = 0; r < 4; ++r)
+        if (n + r < N) o[(size_t)r * ldw] += s[r];
 }
 
 float* g_ws = nullptr;       // caller-owned scratch registered through dm_set_workspace
@@ -632,9 +686,9 @@ int launch_wgrad_halo(const WgHP& p, hipStream_t st) {
     hipLaunchKernelGGL((wgrad3x3_halo_kernel<TW>), dim3((unsigned)(p.blocks * p.splits)), dim3(512), bytes, st, p);
     DM_LAUNCH_CHECK();
     if (p.splits > 1) {
-        const int TC = 9 * (p.C1 + p.C2);
-        const int64_t total4 = (int64_t)p.N * TC / 4;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(total4, (int64_t)256)), dim3(256), 0, st, p.ws, p.dw, p.N, TC, p.ldw, p.splits);
+        const int per_split = p.blocks * 8 * 36 * 64;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(per_split / 256 + cdiv(p.N, 4))), dim3(256), 0, st, (const f32x4*)p.ws, p.dw, p.dbias,
+                           p.N, p.C1 + p.C2, p.nchunks, p.blocks, p.ldw, p.splits);
         DM_LAUNCH_CHECK();
     }
     return DM_OK;
@@ -662,7 +716,7 @@ bool wgrad_halo_plan(const DmWgrad* d, int64_t M, WgHP& hp) {
     if (splits > hp.ntiles) splits = hp.ntiles;
     hp.tiles_per_split = cdiv(hp.ntiles, splits);
     hp.splits = cdiv(hp.ntiles, hp.tiles_per_split);
-    if (hp.splits > 1 && (g_ws == nullptr || (int64_t)hp.splits * d->N * 9 * C * 4 > g_ws_bytes)) return false;
+    if (hp.splits > 1 && (g_ws == nullptr || (int64_t)hp.splits * hp.blocks * (128 * 9 * 64 * 4 + 128 * 4) > g_ws_bytes)) return false;
     return true;
 }
 
