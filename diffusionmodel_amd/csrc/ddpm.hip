@@ -167,7 +167,10 @@ __global__ void sumsq_kernel(const float* g, int64_t n, float* out) {
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
 
-__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hy) {
+// 4 parameters per lane-iteration (16-byte loads / stores of p, g, m, v: 28 B of traffic per parameter, HBM-bound);
+// optionally refreshes the bf16 shadow of the parameters that the conv kernels read (p16[i] = bf16(p[i])).
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hy,
+                                                    bf16* p16) {
     const float lr = hy[0], b1 = hy[1], b2 = hy[2], eps = hy[3], wd = hy[4], max_norm = hy[5], gscale = hy[6], bc1 = hy[7], bc2 = hy[8];
     float coef = gscale;
     if (max_norm > 0.f) {
@@ -176,13 +179,33 @@ __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, int64
         coef *= cc < 1.f ? cc : 1.f;
     }
     const float step_size = lr / bc1, rbc2 = 1.f / sqrtf(bc2), decay = 1.f - lr * wd;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 gv = ((const f32x4*)g)[i], mv = ((const f32x4*)m)[i], vv4 = ((const f32x4*)v)[i], pv = ((const f32x4*)p)[i];
+        f32x4 mo, vo, po;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gg = gv[e] * coef;
+            const float mm = b1 * mv[e] + (1.f - b1) * gg;
+            const float vv = b2 * vv4[e] + (1.f - b2) * gg * gg;
+            mo[e] = mm;
+            vo[e] = vv;
+            po[e] = pv[e] * decay - step_size * mm / (sqrtf(vv) * rbc2 + eps);
+        }
+        ((f32x4*)m)[i] = mo;
+        ((f32x4*)v)[i] = vo;
+        ((f32x4*)p)[i] = po;
+        if (p16) ((bf16x4*)p16)[i] = (bf16x4){(bf16)po[0], (bf16)po[1], (bf16)po[2], (bf16)po[3]};
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {   // tail (< 4 elements)
         const float gg = g[i] * coef;
         const float mm = b1 * m[i] + (1.f - b1) * gg;
         const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
         m[i] = mm;
         v[i] = vv;
-        p[i] = p[i] * decay - step_size * mm / (sqrtf(vv) * rbc2 + eps);
+        const float po = p[i] * decay - step_size * mm / (sqrtf(vv) * rbc2 + eps);
+        p[i] = po;
+        if (p16) p16[i] = (bf16)po;
     }
 }
 
@@ -245,9 +268,15 @@ extern "C" int dm_sumsq(const float* g, int64_t n, float* out, dm_stream_t s) {
     return DM_OK;
 }
 
-extern "C" int dm_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hyper9, dm_stream_t s) {
+extern "C" int dm_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hyper9, void* p_bf16,
+                        dm_stream_t s) {
     DM_CHECK_ARG(p && g && m && v && sumsq && hyper9 && n > 0, "dm_adamw: bad arguments");
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST, p, g, m, v, n, sumsq, hyper9);
+    DM_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && ((uintptr_t)p_bf16 & 7) == 0,
+                 "dm_adamw: the flat buffers must be 16-byte aligned (the bf16 shadow 8-byte)");
+    static int blocks_env = -1;
+    if (blocks_env < 0) { const char* e = getenv("DM_ADAMW_BLOCKS"); blocks_env = e ? atoi(e) : 0; }
+    const int blocks = blocks_env > 0 ? blocks_env : grid_for(n / 4 + 1, 256, 4096);
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, ST, p, g, m, v, n, sumsq, hyper9, (bf16*)p_bf16);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

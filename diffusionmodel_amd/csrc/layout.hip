@@ -35,6 +35,36 @@ __global__ __launch_bounds__(256) void pack_wT_kernel(const float* src, T* dst, 
     }
 }
 
+// table-driven form of pack_wT_kernel: blocks[b] = {entry, n tile, c tile, tt}
+__global__ __launch_bounds__(256) void pack_multi_kernel(const int64_t* __restrict__ entries, const int32_t* __restrict__ taps,
+                                                         const int32_t* __restrict__ blocks, int n_blocks) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const int e = blocks[4 * b], n0 = blocks[4 * b + 1] * 32, c0 = blocks[4 * b + 2] * 32, tt = blocks[4 * b + 3];
+        const int64_t* ent = entries + 8 * (int64_t)e;
+        const float* src = (const float*)ent[0];
+        const int N = (int)ent[2], Tn = (int)ent[3], C = (int)ent[4], Tt = (int)ent[5], Np = (int)ent[6], dtype = (int)ent[7];
+        const int ts = taps[16 * e + tt];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + ty + 8 * j, c = c0 + tx;
+            tile[ty + 8 * j][tx] = (n < N && c < C) ? src[((size_t)n * Tn + ts) * C + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + ty + 8 * j, n = n0 + tx;
+            if (c < C && n < Np) {
+                const size_t o = ((size_t)c * Tt + tt) * Np + n;
+                if (dtype == DM_BF16) ((bf16*)ent[1])[o] = (bf16)tile[tx][ty + 8 * j];
+                else ((float*)ent[1])[o] = tile[tx][ty + 8 * j];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void unpad_dw_kernel(const float* src, float* dst, int64_t rows, int C, int Cp, int accumulate) {
     const int64_t total = rows * C;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -319,6 +349,13 @@ extern "C" int dm_pack_wT(const float* src, void* dst, int dtype, int N, int T_,
     }
     dim3 grid(cdiv(Np, 32), cdiv(C, 32), Tt);
     DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pack_wT_kernel<T>), grid, dim3(256), 0, ST, src, (T*)dst, N, T_, C, Tt, Np, tl));
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_pack_multi(const int64_t* entries, const int32_t* taps, const int32_t* blocks, int n_blocks, dm_stream_t s) {
+    DM_CHECK_ARG(entries && taps && blocks && n_blocks > 0, "dm_pack_multi: bad arguments");
+    hipLaunchKernelGGL(pack_multi_kernel, dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(256), 0, ST, entries, taps, blocks, n_blocks);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

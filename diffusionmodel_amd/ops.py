@@ -13,6 +13,8 @@ Conventions
 """
 import ctypes as C
 
+import weakref
+
 import torch
 
 from . import _lib as L
@@ -35,6 +37,48 @@ def _empty(shape, dtype, ref):
 
 def _zeros(shape, dtype, ref):
     return torch.zeros(shape, dtype=dtype, device=ref.device)
+
+
+class _ZeroArena:
+    """Pre-zeroed fp32 scratch for the many small gradient accumulators of a backward pass (bias / BatchNorm /
+    dense-layer gradients that the kernels add into).  One fill per optimiser step instead of one per tensor: slices
+    are handed out in order and FusedAdamW.step() — which has by then copied every gradient into its flat buffer —
+    re-zeroes the used part.  Without that optimiser (or once the arena is full) `take` falls back to torch.zeros."""
+    CAP = 48 << 20      # bytes
+
+    def __init__(self):
+        self.buf, self.off = None, 0
+
+    def take(self, shape, ref):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if self.buf is None or self.buf.device != ref.device:
+            if self.buf is not None:
+                return torch.zeros(shape, dtype=torch.float32, device=ref.device)
+            self.buf, self.off = torch.zeros(self.CAP // 4, dtype=torch.float32, device=ref.device), 0
+        lo = (self.off + 3) // 4 * 4                  # 16-byte aligned slices
+        if lo + n > self.buf.numel() or torch.cuda.is_current_stream_capturing():
+            return torch.zeros(shape, dtype=torch.float32, device=ref.device)
+        self.off = lo + n
+        return self.buf[lo:lo + n].view(shape)
+
+    def recycle(self):
+        """Everything handed out so far is dead (its values were consumed): zero it again and start over."""
+        if self.buf is not None and self.off:
+            self.buf[:self.off].zero_()
+        self.off = 0
+
+
+ZERO_ARENA = _ZeroArena()
+ARENA_ENABLED = [False]     # switched on by FusedAdamW (the only component that knows when the gradients are dead)
+
+
+def _gzeros(shape, ref):
+    """fp32 zeros for a gradient accumulator that is consumed before the next optimiser step."""
+    if ARENA_ENABLED[0]:
+        return ZERO_ARENA.take(shape, ref)
+    return torch.zeros(shape, dtype=torch.float32, device=ref.device)
 
 
 def _cl(w):
@@ -61,12 +105,20 @@ def _cached(key, w, build):
 
 
 def packed_fwd(w, dtype, cp):
-    """[N][T][cp] weights in `dtype` for dm_conv. fp32 without padding is the master itself."""
+    """[N][T][cp] weights in `dtype` for dm_conv. fp32 without padding is the master itself; bf16 without padding is
+    the optimiser's bf16 shadow of the parameter when there is one (FusedAdamW refreshes it inside its own kernel)."""
     _cl(w)
     n, c = w.shape[0], w.shape[1]
     t = w.shape[2] * w.shape[3]
     if dtype == torch.float32 and cp == c:
         return w
+    shadow = getattr(w, "_dm_shadow16", None)
+    if shadow is not None and dtype == torch.bfloat16 and cp == c:
+        stamp = (w.data_ptr(), w._version)
+        if w._dm_shadow_stamp != stamp:          # modified behind the optimiser's back (load_state_dict, manual init ...)
+            call("dm_cast", ptr(w), ptr(shadow), L.DM_F32, L.DM_BF16, w.numel())
+            w._dm_shadow_stamp = stamp
+        return shadow
 
     def build():
         out = _empty((n, t, cp), dtype, w)
@@ -82,12 +134,72 @@ def packed_T(w, dtype, taps, np_):
     t = w.shape[2] * w.shape[3]
     taps = list(range(t)) if taps is None else list(taps)
 
+    key = ("T", dtype, tuple(taps), np_)
+
     def build():
-        out = _empty((c, len(taps), np_), dtype, w)
+        reg = _T_PACKS.get((id(w), key))
+        if reg is not None and reg[0]() is w:
+            out = reg[1]                          # re-pack in place: the batched refresh keeps pointing at this tensor
+        else:
+            out = _empty((c, len(taps), np_), dtype, w)
+            if len(taps) <= 16:
+                _T_PACKS[(id(w), key)] = (weakref.ref(w), out, (n, t, c, tuple(taps), np_, dt(dtype)))
+                _T_TABLES.clear()
         arr = (C.c_int32 * len(taps))(*taps)
         call("dm_pack_wT", ptr(w), ptr(out), dt(dtype), n, t, c, len(taps), arr, np_)
         return out
-    return _cached(("T", dtype, tuple(taps), np_), w, build)
+    return _cached(key, w, build)
+
+
+_T_PACKS = {}        # (id(param), key) -> (weakref(param), packed tensor, geometry): every transposed pack ever requested
+_T_TABLES = {}       # device tables of dm_pack_multi, rebuilt when the registry changes
+
+
+def refresh_packs():
+    """Re-pack every registered transposed weight pack with ONE launch (after an optimiser step) and re-stamp the
+    per-parameter caches, so the backward pass of the next step finds them fresh."""
+    if not _T_PACKS:
+        return
+    if not _T_TABLES:
+        ents, taps_rows, blocks = [], [], []
+        for k in list(_T_PACKS):
+            wr, out, (n, t, c, taps, np_, dty) = _T_PACKS[k]
+            w = wr()
+            if w is None:
+                del _T_PACKS[k]
+                continue
+            e = len(ents)
+            ents.append((w.data_ptr(), out.data_ptr(), n, t, c, len(taps), np_, dty))
+            taps_rows.append(list(taps) + [0] * (16 - len(taps)))
+            for tt in range(len(taps)):
+                for ct in range((c + 31) // 32):
+                    for nt in range((np_ + 31) // 32):
+                        blocks.append((e, nt, ct, tt))
+        if not ents:
+            return
+        dev = next(iter(_T_PACKS.values()))[1].device
+        _T_TABLES["ents"] = torch.tensor(ents, dtype=torch.int64).to(dev)
+        _T_TABLES["taps"] = torch.tensor(taps_rows, dtype=torch.int32).to(dev)
+        _T_TABLES["blocks"] = torch.tensor(blocks, dtype=torch.int32).to(dev)
+        _T_TABLES["ptrs"] = [e[0] for e in ents]
+        _T_TABLES["keys"] = list(_T_PACKS)
+    # a parameter whose storage moved since the tables were built falls back to the lazy per-tensor path
+    keys = _T_TABLES["keys"]
+    for k, p0 in zip(keys, _T_TABLES["ptrs"]):
+        w = _T_PACKS[k][0]() if k in _T_PACKS else None
+        if w is None or w.data_ptr() != p0:
+            _T_TABLES.clear()
+            return
+    call("dm_pack_multi", ptr(_T_TABLES["ents"]), ptr(_T_TABLES["taps"]), ptr(_T_TABLES["blocks"]), _T_TABLES["blocks"].shape[0])
+    for k in keys:
+        wr, out, _ = _T_PACKS[k]
+        w = wr()
+        stamp = (w.data_ptr(), w._version, _EPOCH[0])
+        store = getattr(w, "_dm_cache", None)
+        if store is None or store[0] != stamp:
+            store = (stamp, {})
+            w._dm_cache = store
+        store[1][k[1]] = out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -262,7 +374,7 @@ class ConvBnAct(torch.autograd.Function):
             if ctx.train:
                 s1, s2 = dbeta, dgamma
             else:
-                s1 = s2 = _zeros((N,), torch.float32, g)
+                s1 = s2 = _gzeros((N,), g)
             call("dm_bn_act_bwd_apply", ptr(z), ptr(g), ptr(dz), dt(dtype), M, N, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
                  spec.act, ptr(s1), ptr(s2))
             ldy = N
@@ -313,7 +425,7 @@ class ConvBnAct(torch.autograd.Function):
             wg_geom = dict(dtype=dtype, B=B, Hi=Hi, Wi=Wi, C1=C1, C2=C2, Hq=Ho, Wq=Wo, sy=s, sx=s, T=T, KW=kw, ty=1, tx=1,
                            oy0=-p, ox0=-p, Ho=Ho, Wo=Wo, N=N, ldy=ldy, ldw=T * Cp)
             if ctx.bias_present:
-                db = _zeros((N,), torch.float32, g)
+                db = _gzeros((N,), g)
             if Cp == Cin:
                 if main is not None:
                     tgt = main
@@ -440,7 +552,7 @@ class GroupNormAct(torch.autograd.Function):
         B, H, W, Cc = x.shape
         g = g.contiguous()
         dx = _empty(x.shape, x.dtype, x)
-        dgamma, dbeta = _zeros((Cc,), torch.float32, x), _zeros((Cc,), torch.float32, x)
+        dgamma, dbeta = _gzeros((Cc,), x), _gzeros((Cc,), x)
         call("dm_gn_act_bwd", ptr(x), ptr(g), ptr(dx), dt(x), B, H * W, Cc, groups, ptr(gamma), ptr(beta), act, ptr(mean), ptr(rstd),
              ptr(dgamma), ptr(dbeta))
         return dx, dgamma, dbeta, None, None
@@ -481,7 +593,7 @@ def _lin_bwd(x, w, g, dx, dw, db):
         _conv_call(g, None, ptr(wt), N, dx, dtype=torch.float32, B=M, Hi=1, Wi=1, C1=N, C2=0, Hq=1, Wq=1, sy=1, sx=1,
                    T=1, KW=1, ty=1, tx=1, oy0=0, ox0=0, Ho=1, Wo=1, N=K)
     if dw is not None or db is not None:
-        tgt = dw if dw is not None else _zeros((N, K), torch.float32, x)
+        tgt = dw if dw is not None else _gzeros((N, K), x)
         _wgrad_call(g, x, None, tgt, db, dtype=torch.float32, B=M, Hi=1, Wi=1, C1=K, C2=0, Hq=1, Wq=1, sy=1, sx=1, T=1,
                     KW=1, ty=1, tx=1, oy0=0, ox0=0, Ho=1, Wo=1, N=N, ldy=N, ldw=K)
 
@@ -504,8 +616,8 @@ class Linear(torch.autograd.Function):
         M, K = x.shape
         N = w.shape[0]
         dx = _empty((M, K), torch.float32, x) if ctx.needs_input_grad[0] else None
-        dw = _zeros((N, K), torch.float32, x) if ctx.needs_input_grad[1] else None
-        db = _zeros((N,), torch.float32, x) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        dw = _gzeros((N, K), x) if ctx.needs_input_grad[1] else None
+        db = _gzeros((N,), x) if (ctx.has_b and ctx.needs_input_grad[2]) else None
         _lin_bwd(x, w, g, dx, dw, db)
         return dx, dw, db
 
@@ -576,7 +688,7 @@ class BnActMatrix(torch.autograd.Function):
         call("dm_col_reduce", ptr(p1), nblk, Cc, ptr(dbeta), 0)
         call("dm_col_reduce", ptr(p2), nblk, Cc, ptr(dgamma), 0)
         dz = _empty(z.shape, torch.float32, z)
-        s1, s2 = (dbeta, dgamma) if train else (_zeros((Cc,), torch.float32, z),) * 2
+        s1, s2 = (dbeta, dgamma) if train else (_gzeros((Cc,), z),) * 2
         call("dm_bn_act_bwd_apply", ptr(z), ptr(g), ptr(dz), L.DM_F32, M, Cc, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act,
              ptr(s1), ptr(s2))
         return dz.reshape(shape), dgamma, dbeta, None, None, None
@@ -623,7 +735,7 @@ class SeResidual(torch.autograd.Function):
         x2, y, hid, gh, logit, sg, w1, w2 = ctx.saved_tensors
         f = lambda *s: _empty(s, torch.float32, g)
         dsg, dlogit, dgh, dhid, dy = f(B, Cc), f(B, Cc), f(B, R), f(B, R), f(B, Cc)
-        dw1, dw2 = _zeros((R, Cc), torch.float32, g), _zeros((Cc, R), torch.float32, g)
+        dw1, dw2 = _gzeros((R, Cc), g), _gzeros((Cc, R), g)
         call("dm_scale_residual_bwd_reduce", ptr(g), ptr(x2), dt(dtype), B, H * W, Cc, inv, ptr(dsg))
         call("dm_act_bwd", ptr(logit), ptr(dsg), ptr(dlogit), B * Cc, ACT_SIGMOID)
         _lin_bwd(gh, w2, dlogit, dgh, dw2, None)
@@ -672,7 +784,7 @@ class SigMix(torch.autograd.Function):
         y, gamma = ctx.saved_tensors
         g = g.contiguous()
         dy = _empty(y.shape, torch.float32, y)
-        dgamma = _zeros((1,), torch.float32, y)
+        dgamma = _gzeros((1,), y)
         call("dm_sigmix_bwd", ptr(g), ptr(y), ptr(gamma), ptr(dy), ptr(dgamma), y.numel())
         return g, dy, dgamma
 
@@ -696,7 +808,7 @@ class CaGate(torch.autograd.Function):
         g = g.contiguous()
         dx = _empty(x.shape, x.dtype, x)
         dlh, dlw = _empty(lh.shape, torch.float32, x), _empty(lw.shape, torch.float32, x)
-        dab = _zeros((4,), torch.float32, x)
+        dab = _gzeros((4,), x)
         call("dm_ca_gate_bwd", ptr(x), ptr(g), ptr(lh), ptr(lw), ptr(alpha), ptr(beta), ptr(dx), ptr(dlh), ptr(dlw), ptr(dab), dt(x),
              B, H, W, Cc)
         return dx, dlh, dlw, dab[0:1], dab[1:2]

@@ -37,6 +37,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.total = total
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_p16 = torch.zeros(total, dtype=torch.bfloat16, device=dev)     # bf16 shadow, refreshed by the AdamW kernel
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self._slots = []
@@ -50,6 +51,8 @@ class FusedAdamW(torch.optim.Optimizer):
                     phys.copy_(p.data.permute(0, 2, 3, 1))
                     p.data = phys.permute(0, 3, 1, 2)
                     p.main_grad = self.flat_g[off:off + n].view(O, kh, kw, I)
+                    p._dm_shadow16 = self.flat_p16[off:off + n].view(O, kh * kw, I)
+                    p._dm_shadow_stamp = None
                 else:
                     flat = self.flat_p[off:off + n].view(p.shape)
                     flat.copy_(p.data)
@@ -57,7 +60,17 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._slots.append((p, off, n))
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._hyper = torch.zeros(9, dtype=torch.float32, device=dev)
+        self.refresh_shadow()
         ops.bump_weight_epoch()
+        ops.ARENA_ENABLED[0] = True                  # step() recycles the gradient scratch arena
+
+    def refresh_shadow(self):
+        """Recompute the whole bf16 shadow from the fp32 masters (construction, after a parameter broadcast or any
+        other write to `flat_p` that did not go through step())."""
+        call("dm_cast", ptr(self.flat_p), ptr(self.flat_p16), ops.L.DM_F32, ops.L.DM_BF16, self.total)
+        for p, _, _ in self._slots:
+            if hasattr(p, "_dm_shadow16"):
+                p._dm_shadow_stamp = (p.data_ptr(), p._version)
 
     # ------------------------------------------------------------------------------------------
     def zero_grad(self, set_to_none=True):
@@ -87,6 +100,7 @@ class FusedAdamW(torch.optim.Optimizer):
             self._table = table
         for p, _, _ in self._slots:
             p.grad = None
+        ops.ZERO_ARENA.recycle()                     # every small gradient accumulator has been copied out: one fill re-zeroes them
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -102,8 +116,9 @@ class FusedAdamW(torch.optim.Optimizer):
         self._sumsq.zero_()
         call("dm_sumsq", ptr(self.flat_g), self.total, ptr(self._sumsq))
         call("dm_adamw", ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.total,
-             ptr(self._sumsq), ptr(self._hyper))
+             ptr(self._sumsq), ptr(self._hyper), ptr(self.flat_p16))
         ops.bump_weight_epoch()
+        ops.refresh_packs()                          # every transposed (input-gradient) weight pack, one launch
 
     def grad_norm(self):
         """Global gradient norm of the last step (device tensor, no host sync)."""

@@ -90,6 +90,10 @@ int dm_set_workspace(void* ws, int64_t bytes);
 int dm_pack_w(const float* src, void* dst, int dtype, int N, int T, int C, int Cp, dm_stream_t s);
 int dm_pack_wT(const float* src, void* dst, int dtype, int N, int T, int C, int Tt, const int32_t* taps, int Np, dm_stream_t s);
 int dm_unpad_dw(const float* src, float* dst, int N, int T, int C, int Cp, int accumulate, dm_stream_t s);
+/* Many dm_pack_wT in one launch (all transposed packs of a model after an optimiser step).  Device tables:
+ *   entries[e] = {src, dst, N, T, C, Tt, Np, dtype} as 8 x int64;  taps[e][16] int32 (Tt <= 16);
+ *   blocks[b]  = {e, n tile, c tile, tt} int32: one 32 x 32 tile of entry e per workgroup. */
+int dm_pack_multi(const int64_t* entries, const int32_t* taps, const int32_t* blocks, int n_blocks, dm_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm2d in training mode (new_scripy.py:79-80,185-186,190-191,218-219,226-227) on an [M][C] matrix
@@ -229,7 +233,9 @@ int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, dm_stream_t 
 int dm_sumsq(const float* g, int64_t n, float* out /* one float, += */, dm_stream_t s);
 /* clip coefficient = min(1, max_norm/(sqrt(*sumsq)*gscale + 1e-6)); gscale folds 1/world etc.
  * hyper = {lr, beta1, beta2, eps, weight_decay, max_norm, gscale, bias_corr1, bias_corr2} (device) */
-int dm_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hyper9, dm_stream_t s);
+/* p_bf16 (may be NULL): bf16 shadow of the parameters, refreshed in the same pass (p_bf16[i] = bf16(p[i])) — the conv
+ * kernels read it as their packed forward weights, so no per-layer cast launch follows an optimiser step */
+int dm_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hyper9, void* p_bf16, dm_stream_t s);
 
 /* Evaluation helpers of the drivers (new_scripy.py:1188-1250): per image pair (a_i, b_i), n_per_image floats each,
  * out[i] = {sum a, sum b, sum a^2, sum b^2, sum ab, min a, min b, n} as 8 doubles — global-statistics SSIM and PSNR
