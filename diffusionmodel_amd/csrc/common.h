@@ -134,6 +134,10 @@ template <> __device__ inline void store_vec<bf16>(bf16* p, const float* f) {
     *(bf16x8*)p = v;
 }
 
+// caller-owned scratch registered through dm_set_workspace (runtime.hip): split partial sums of the MFMA kernels
+extern float* dm_g_ws;
+extern int64_t dm_g_ws_bytes;
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int grid_for(int64_t work_items, int block, int cap = 256 * 16) {
     int64_t g = (work_items + block - 1) / block;

@@ -45,7 +45,22 @@ struct ConvP {
     int act, out_nchw;
     int B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0;
     int Ho, Wo, osy, osx, ooy, oox, N, ldw, ldc, coff, M;
+    // split-K (LDS-DMA kernels): `splits` workgroups share an output tile, each takes `kper` k-steps (gather kernel) or
+    // channel chunks (halo kernel) and leaves its accumulators in ws; splitk_epilogue_kernel adds them up and finishes
+    int splits, kper;
+    float* ws;
 };
+
+// raw accumulators of one 128 x BN tile as they sit in the registers: [tile][wave][nt][mt][lane] float4 (1 KiB per store)
+template <int BN>
+__device__ __forceinline__ void store_partial(const ConvP& p, const f32x4 (&acc)[BN / 32][4], int split, int tiles, int tile, int wave, int lane) {
+    constexpr int NT = BN / 32;
+    f32x4* dst = (f32x4*)p.ws + ((((size_t)split * tiles + tile) * 4 + wave) * (NT * 4)) * 64 + lane;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) dst[(nt * 4 + mt) * 64] = acc[nt][mt];
+}
 
 __device__ __attribute__((aligned(128))) unsigned int g_zero_page[64];  // source of every padded 16-B vector (v2)
 
@@ -319,7 +334,9 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvP p) {
     const int wm = wave & 1, wn = wave >> 1;
     const int fr = lane & 15, fg = lane >> 4;
     const int nb_n = (p.N + BN - 1) / BN;
-    const int bid = remap_xcd(blockIdx.x, gridDim.x);
+    const int ntiles = gridDim.x / p.splits;
+    const int split = blockIdx.x / ntiles;
+    const int bid = remap_xcd(blockIdx.x - split * ntiles, ntiles);
     const int mb = bid / nb_n, nb = bid - mb * nb_n;
     const int m0 = mb * BM, n0 = nb * BN;
     const int C = p.C1 + p.C2;
@@ -363,7 +380,10 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvP p) {
         offB[j] = (okB[j] ? n : 0) * p.ldw;
     }
 
-    int ld_t = 0, ld_ky = 0, ld_kx = 0, ld_c0 = 0;       // state of the NEXT k-step to be issued (wave-uniform)
+    const int spt = (C + BK - 1) / BK;                   // k-steps per tap
+    const int ks_lo = split * p.kper;                    // this split's k-steps [ks_lo, ks_lo + nsteps)
+    int ld_t = ks_lo / spt, ld_c0 = (ks_lo - ld_t * spt) * BK;   // state of the NEXT k-step to be issued (wave-uniform)
+    int ld_ky = ld_t / p.KW, ld_kx = ld_t - ld_ky * p.KW;
     auto issue = [&](int stage) {
         char* sA = smem + stage * STAGE;
         char* sB = sA + A_BYTES;
@@ -402,7 +422,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nsteps = p.T * ((C + BK - 1) / BK);
+    const int nsteps = min(p.kper, p.T * spt - ks_lo);
     // prologue: NS-1 stages in flight
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
@@ -420,8 +440,37 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvP p) {
         prod = cons;
         cons = cons + 1 == NS ? 0 : cons + 1;
     }
+    if (p.splits > 1) {
+        store_partial<BN>(p, acc, split, ntiles, bid, wave, lane);
+        return;
+    }
     __syncthreads();                     // the epilogue reuses the LDS for the statistics fold
     conv_epilogue<T, BN>(p, acc, smem, tid, wm, wn, fr, fg, mb, m0, n0);
+}
+
+// sums the split partials of a 128 x BN tile back into the accumulator registers and runs the ordinary epilogue
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvP p) {
+    constexpr int NT = BN / 32;
+    __shared__ __attribute__((aligned(16))) char smem[4 * BN * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1, fr = lane & 15, fg = lane >> 4;
+    const int nb_n = (p.N + BN - 1) / BN;
+    const int tiles = gridDim.x, bid = blockIdx.x;
+    const int mb = bid / nb_n, nb = bid - mb * nb_n;
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < p.splits; ++k) {
+        const f32x4* src = (const f32x4*)p.ws + ((((size_t)k * tiles + bid) * 4 + wave) * (NT * 4)) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] += src[(i * 4 + j) * 64];
+    }
+    conv_epilogue<T, BN>(p, acc, smem, tid, wm, wn, fr, fg, mb, mb * BM, nb * BN);
 }
 
 // =================================================================================================
@@ -457,7 +506,9 @@ constexpr int SRD_FLAGS = 0x00020000;
 
 template <int TW, bool FLIP>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
-    constexpr int TH = 256 / TW, HS = TW + 8, HR = TH + 2, NP = HR * HS / 8;
+    // TW = 8 (8x8 images): the tile is FOUR whole images laid side by side in the halo, each with its own zero columns
+    // ([0 A 0][0 B 0][0 C 0][0 D 0], 10 columns apiece): rows stay multiples of 8 pixels, a wave (64 pixels) is one image
+    constexpr int TH = TW == 8 ? 8 : 256 / TW, HS = TW == 8 ? 40 : TW + 8, HR = TH + 2, NP = HR * HS / 8;
     static_assert(NP <= HALO_PIECES, "halo does not fit");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [halo 0][halo 1][w 0][w 1][w 2]
     char* const sW = smem + 2 * HALO_BYTES;
@@ -467,13 +518,16 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
     const int wm4 = wave & 3, wn = wave >> 2;
     const int fr = lane & 15, fg = lane >> 4;
     const int nb_n = (p.N + 127) >> 7;
-    const int bid = remap_xcd(blockIdx.x, gridDim.x);
+    const int ntiles = gridDim.x / p.splits;
+    const int split = blockIdx.x / ntiles;
+    const int bid = remap_xcd(blockIdx.x - split * ntiles, ntiles);
     const int mb = bid / nb_n, nb = bid - mb * nb_n;
     const int m0 = mb * 256, n0 = nb * 128;
     const int C = p.C1 + p.C2;
-    const int nchunks = C >> 6;
-    const int tiles_img = (p.Hi * TW) >> 8;
-    const int b = mb / tiles_img, y0 = (mb - b * tiles_img) * TH;
+    const int c_lo = split * p.kper;                       // this split's channel chunks [c_lo, nchunks)
+    const int nchunks = min(C >> 6, c_lo + p.kper);
+    const int tiles_img = TW == 8 ? 1 : (p.Hi * TW) >> 8;
+    const int b = TW == 8 ? mb * 4 : mb / tiles_img, y0 = TW == 8 ? 0 : (mb - b * tiles_img) * TH;
 
     const int pix_img = p.B * p.Hi * TW;
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.N * p.ldw * 2, SRD_FLAGS);
@@ -487,9 +541,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
         const int q = min(wave + 8 * i, NP - 1);           // surplus pieces re-fetch the last one (same bytes, same place)
         const int hp = q * 8 + lrow;
         const int hy = hp / HS, hx = hp - hy * HS;
-        const int y = y0 + hy - 1, x = hx - 1;
-        const bool ok = (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)TW;
-        const int pix = (b * p.Hi + y) * TW + x;
+        const int img = TW == 8 ? hx / 10 : 0;                     // TW = 8: image of the tile this halo column belongs to
+        const int y = y0 + hy - 1, x = TW == 8 ? hx - img * 10 - 1 : hx - 1;
+        const bool ok = (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)TW && img < 4;
+        const int pix = ((b + img) * p.Hi + y) * TW + x;
         hv1[i] = ok ? (unsigned)(pix * p.C1 * 2 + slotb) : OOB;
         hv2[i] = ok ? (unsigned)(pix * p.C2 * 2 + slotb) : OOB;
     }
@@ -502,13 +557,20 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
     int hoff[3][2][4];                                     // pixel-operand fragment addresses in the current halo buffer
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        const int g = wm4 * 4 + mt;
-        const int ly = g / (TW / 16), lx0 = (g - ly * (TW / 16)) * 16;
-        const int base = (ly * HS + lx0 + fr) * ROWB;
+        int ly, col;                                        // halo row / column of this lane's pixel of the 16-pixel group (tap 0,0)
+        if constexpr (TW == 8) {                            // group = rows 2 mt, 2 mt + 1 of image wm4
+            ly = mt * 2 + (fr >> 3);
+            col = wm4 * 10 + (fr & 7);
+        } else {
+            const int g = wm4 * 4 + mt;
+            ly = g / (TW / 16);
+            col = (g - ly * (TW / 16)) * 16 + fr;
+        }
+        const int base = (ly * HS + col) * ROWB;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) hoff[kx][sub][mt] = base + (((sub * 4 + fg) ^ ((fr + kx) & 7)) << 4);
+            for (int sub = 0; sub < 2; ++sub) hoff[kx][sub][mt] = base + (((sub * 4 + fg) ^ ((col + kx) & 7)) << 4);
     }
     int woff[2][4];                                        // weight-operand fragment addresses within a stage
 #pragma unroll
@@ -543,13 +605,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
-    for (int i = 0; i < 7; ++i) issue_h(i, 0, 0);
-    issue_w(0, 0, 0);
-    issue_w(1, 0, 1);
+    for (int i = 0; i < 7; ++i) issue_h(i, c_lo, 0);
+    issue_w(0, c_lo, 0);
+    issue_w(1, c_lo, 1);
     int hdelta = HALO_BYTES;
     {
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            const int nbuf = (chunk + 1) & 1;
+        for (int chunk = c_lo; chunk < nchunks; ++chunk) {
+            const int nbuf = (chunk - c_lo + 1) & 1;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 // everything older than the previous step's group (2 weight pieces + its halo piece) has landed
@@ -586,6 +648,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
     wait_vmcnt<0>();                     // the surplus (out-of-range) pieces of the last steps
     __syncthreads();                     // the epilogue reuses the LDS for the statistics fold
     const int half = wm4 >> 1;
+    if (p.splits > 1) {                  // the two 128-row halves are tiles 2 mb, 2 mb + 1 of the 128 x 128 epilogue kernel
+        store_partial<128>(p, acc, split, ntiles * 2, (mb * 2 + half) * nb_n + nb, (wm4 & 1) + 2 * wn, lane);
+        return;
+    }
     const int tidh = (((wave & 1) + 2 * wn) << 6) + lane;
     conv_epilogue<bf16, 128>(p, acc, smem + half * 4096, tidh, wm4 & 1, wn, fr, fg, mb * 2 + half, m0 + half * 128, n0);
 }
@@ -626,9 +692,25 @@ int launch_halo(const ConvP& p, hipStream_t st) {
         if (e != hipSuccess) { dm_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", HALO_LDS, hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
-    const int64_t grid = (int64_t)(p.M / 256) * cdiv(p.N, 128);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<TW, FLIP>), dim3((unsigned)grid), dim3(512), HALO_LDS, st, p);
+    const int tiles = (p.M / 256) * cdiv(p.N, 128);
+    ConvP q = p;
+    // few tiles, deep K (the 8x8 / 16x16 layers): split the channel chunks over workgroups until the chip is full
+    const int nchunks = (p.C1 + p.C2) / 64;
+    if (tiles <= 128 && nchunks >= 4 && dm_g_ws != nullptr) {
+        int splits = 256 / tiles;
+        if (splits > nchunks / 2) splits = nchunks / 2;
+        if (splits >= 2 && (int64_t)splits * tiles * 2 * (128 * 128 * 4) <= dm_g_ws_bytes) {
+            q.kper = cdiv(nchunks, splits);
+            q.splits = cdiv(nchunks, q.kper);
+            q.ws = dm_g_ws;
+        }
+    }
+    hipLaunchKernelGGL((conv3x3_halo_kernel<TW, FLIP>), dim3((unsigned)(tiles * q.splits)), dim3(512), HALO_LDS, st, q);
     DM_LAUNCH_CHECK();
+    if (q.splits > 1) {
+        hipLaunchKernelGGL((splitk_epilogue_kernel<bf16, 128>), dim3((unsigned)(tiles * 2)), dim3(256), 0, st, q);
+        DM_LAUNCH_CHECK();
+    }
     return DM_OK;
 }
 
@@ -638,8 +720,12 @@ bool halo_eligible(const ConvP& p) {
     // forward taps (y-1+ky, x-1+kx), or the input-gradient's mirrored traversal (y+1-ky, x+1-kx)
     if (!((p.ty == 1 && p.tx == 1 && p.oy0 == -1 && p.ox0 == -1) || (p.ty == -1 && p.tx == -1 && p.oy0 == 1 && p.ox0 == 1))) return false;
     if (p.Hq != p.Hi || p.Wq != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi || p.osy != 1 || p.osx != 1 || p.ooy != 0 || p.oox != 0) return false;
-    if (p.Wi != 16 && p.Wi != 32 && p.Wi != 64) return false;
-    if ((p.Hi * p.Wi) % 256 != 0 || p.C1 % 64 != 0 || p.C2 % 64 != 0) return false;
+    if (p.Wi == 8) {                                                   // four whole 8x8 images per tile
+        if (p.Hi != 8 || p.B % 4 != 0) return false;
+    } else if ((p.Wi != 16 && p.Wi != 32 && p.Wi != 64) || (p.Hi * p.Wi) % 256 != 0) {
+        return false;
+    }
+    if (p.C1 % 64 != 0 || p.C2 % 64 != 0) return false;
     const int64_t pix = (int64_t)p.B * p.Hi * p.Wi;
     const int64_t cmax = p.C1 > p.C2 ? p.C1 : p.C2;
     return pix * cmax * 2 < (1ll << 31) && (int64_t)p.N * p.ldw * 2 < (1ll << 31);
@@ -652,7 +738,8 @@ int launch_conv(const ConvP& p, bool small_offsets, hipStream_t st) {
             const bool flip = p.ty < 0;
             if (p.Wi == 64) return flip ? launch_halo<64, true>(p, st) : launch_halo<64, false>(p, st);
             if (p.Wi == 32) return flip ? launch_halo<32, true>(p, st) : launch_halo<32, false>(p, st);
-            return flip ? launch_halo<16, true>(p, st) : launch_halo<16, false>(p, st);
+            if (p.Wi == 16) return flip ? launch_halo<16, true>(p, st) : launch_halo<16, false>(p, st);
+            return flip ? launch_halo<8, true>(p, st) : launch_halo<8, false>(p, st);
         }
     }
     const int mblocks = cdiv(p.M, BM);
@@ -660,16 +747,37 @@ int launch_conv(const ConvP& p, bool small_offsets, hipStream_t st) {
     if (p.N <= 32) bn = 32;
     else if (p.N <= 64) bn = 64;
     else if ((int64_t)mblocks * cdiv(p.N, 128) < 256) bn = 64;  // small problems: more, smaller tiles
-    const int64_t grid = (int64_t)mblocks * cdiv(p.N, bn);
+    const int64_t tiles = (int64_t)mblocks * cdiv(p.N, bn);
     int variant = small_offsets ? g_variant : 1;
     // fewer workgroups than CUs: nothing else hides the load latency, so run the ring 3 steps ahead instead of 1
-    if (variant == 5 && grid < 256) variant = 4;
+    if (variant == 5 && tiles <= 256) variant = 4;
+    ConvP q = p;
+    // a handful of tiles with a long reduction (dense layers on pooled vectors, the 4x4 / 8x8 bottleneck convolutions):
+    // split the k-steps over workgroups, partial tiles to the workspace, splitk_epilogue_kernel finishes
+    if (variant >= 2 && tiles <= 128 && dm_g_ws != nullptr) {
+        const int bk = 128 / (int)sizeof(T);
+        const int ksteps = p.T * cdiv(p.C1 + p.C2, bk);
+        int splits = (int)(256 / tiles);
+        if (splits > ksteps / 4) splits = ksteps / 4;
+        if (splits >= 2 && (int64_t)splits * tiles * (128 * bn * 4) <= dm_g_ws_bytes) {
+            q.kper = cdiv(ksteps, splits);
+            q.splits = cdiv(ksteps, q.kper);
+            q.ws = dm_g_ws;
+        }
+    }
+    const int64_t grid = tiles * q.splits;
     int rc;
-    if (bn == 128) rc = launch_bn<T, 128>(p, grid, variant, st);
-    else if (bn == 64) rc = launch_bn<T, 64>(p, grid, variant, st);
-    else rc = launch_bn<T, 32>(p, grid, variant, st);
+    if (bn == 128) rc = launch_bn<T, 128>(q, grid, variant, st);
+    else if (bn == 64) rc = launch_bn<T, 64>(q, grid, variant, st);
+    else rc = launch_bn<T, 32>(q, grid, variant, st);
     if (rc) return rc;
     DM_LAUNCH_CHECK();
+    if (q.splits > 1) {
+        if (bn == 128) hipLaunchKernelGGL((splitk_epilogue_kernel<T, 128>), dim3((unsigned)tiles), dim3(256), 0, st, q);
+        else if (bn == 64) hipLaunchKernelGGL((splitk_epilogue_kernel<T, 64>), dim3((unsigned)tiles), dim3(256), 0, st, q);
+        else hipLaunchKernelGGL((splitk_epilogue_kernel<T, 32>), dim3((unsigned)tiles), dim3(256), 0, st, q);
+        DM_LAUNCH_CHECK();
+    }
     return DM_OK;
 }
 
@@ -704,6 +812,7 @@ extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
     p.T = d->T; p.KW = d->KW; p.ty = d->ty; p.tx = d->tx; p.oy0 = d->oy0; p.ox0 = d->ox0;
     p.Ho = d->Ho; p.Wo = d->Wo; p.osy = d->osy; p.osx = d->osx; p.ooy = d->ooy; p.oox = d->oox;
     p.N = d->N; p.ldw = d->ldw; p.ldc = d->ldc; p.coff = d->coff; p.M = (int)M;
+    p.splits = 1; p.kper = 1 << 24; p.ws = nullptr;
     // the LDS-DMA kernel indexes with unsigned 32-bit element offsets (with a margin for the halo arithmetic)
     const int64_t in_elems = (int64_t)d->B * d->Hi * d->Wi * (d->C1 > d->C2 ? d->C1 : d->C2);
     const int64_t w_elems = (int64_t)d->N * d->ldw;

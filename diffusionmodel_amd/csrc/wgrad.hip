@@ -628,8 +628,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restri
         if (n + r < N) o[(size_t)r * ldw] += s[r];
 }
 
-float* g_ws = nullptr;       // caller-owned scratch registered through dm_set_workspace
-int64_t g_ws_bytes = 0;
 int g_wgrad_halo = 1;
 
 int g_wgrad_variant = 2;
@@ -706,7 +704,7 @@ bool wgrad_halo_plan(const DmWgrad* d, int64_t M, WgHP& hp) {
     if (M * cmax * 2 >= (1ll << 31) || M * d->ldy * 2 >= (1ll << 31)) return false;
     if (((uintptr_t)d->dy & 15) || ((uintptr_t)d->in1 & 15) || ((uintptr_t)d->in2 & 15)) return false;
     const int C = d->C1 + d->C2;
-    hp.dy = (const char*)d->dy; hp.in1 = (const char*)d->in1; hp.in2 = (const char*)d->in2; hp.dw = d->dw; hp.dbias = d->dbias; hp.ws = g_ws;
+    hp.dy = (const char*)d->dy; hp.in1 = (const char*)d->in1; hp.in2 = (const char*)d->in2; hp.dw = d->dw; hp.dbias = d->dbias; hp.ws = dm_g_ws;
     hp.B = d->B; hp.Hi = d->Hi; hp.C1 = d->C1; hp.C2 = d->C2; hp.N = d->N; hp.ldy = d->ldy; hp.ldw = d->ldw;
     hp.ntiles = (int)(M / 128);
     hp.nchunks = C / 64;
@@ -716,15 +714,8 @@ bool wgrad_halo_plan(const DmWgrad* d, int64_t M, WgHP& hp) {
     if (splits > hp.ntiles) splits = hp.ntiles;
     hp.tiles_per_split = cdiv(hp.ntiles, splits);
     hp.splits = cdiv(hp.ntiles, hp.tiles_per_split);
-    if (hp.splits > 1 && (g_ws == nullptr || (int64_t)hp.splits * hp.blocks * (128 * 9 * 64 * 4 + 128 * 4) > g_ws_bytes)) return false;
+    if (hp.splits > 1 && (dm_g_ws == nullptr || (int64_t)hp.splits * hp.blocks * (128 * 9 * 64 * 4 + 128 * 4) > dm_g_ws_bytes)) return false;
     return true;
-}
-
-extern "C" int dm_set_workspace(void* ws, int64_t bytes) {
-    DM_CHECK_ARG((ws == nullptr) == (bytes == 0) && bytes >= 0 && ((uintptr_t)ws & 15) == 0, "dm_set_workspace: need a 16-byte aligned buffer and its size (or NULL, 0)");
-    g_ws = (float*)ws;
-    g_ws_bytes = bytes;
-    return DM_OK;
 }
 
 extern "C" int dm_set_wgrad_variant(int variant) {

@@ -208,6 +208,7 @@ def refresh_packs():
 def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0,
                Ho, Wo, N, osy=1, osx=1, ooy=0, oox=0, ldc=None, coff=0, scale=None, shift=None, act=ACT_NONE,
                psum=None, psq=None, out_nchw=False):
+    L.ensure_workspace()          # split-K partial tiles of small, deep problems
     d = L.DmConv()
     d.in1, d.in2, d.w = ptr(in1), ptr(in2), w_ptr
     d.scale, d.shift, d.out, d.psum, d.psq = ptr(scale), ptr(shift), ptr(out), ptr(psum), ptr(psq)

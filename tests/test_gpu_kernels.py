@@ -121,6 +121,8 @@ HALO_CASES = [
     (1, 64, 0, 192, 64),     # two n-tiles, the second half empty; 16 tiles per image
     (2, 64, 128, 64, 16),    # concatenated sources with different channel counts
     (3, 192, 0, 136, 32),    # three chunks, ragged N, odd batch
+    (4, 64, 0, 128, 8),      # 8x8 images: four whole images side by side in one halo
+    (8, 128, 64, 192, 8),    # 8x8, two tiles, concatenated sources, two n-tiles
 ]
 
 
