@@ -410,8 +410,9 @@ struct WgHP {
 
 template <int TW>
 __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
-    constexpr int R = 128 / TW, HS = TW + 8, HR = R + 2, XP = HR * HS / 8;    // 36 / 30 / 30 halo pieces
-    constexpr int HI = (TW == 16 ? HS : 16) * 128;                            // byte offset of the k-step's second 16 pixels in the halo
+    // TW = 8 (8x8 images): a tile is TWO whole images side by side in the halo ([0 A 0][0 B 0], 10 columns apiece, HS = 24)
+    constexpr int R = TW == 8 ? 8 : 128 / TW, HS = TW == 8 ? 24 : TW + 8, HR = R + 2, XP = HR * HS / 8;    // 36 / 30 / 30 / 30 halo pieces
+    constexpr int HI = (TW == 8 ? 2 * HS : TW == 16 ? HS : 16) * 128;         // byte offset of the k-step's second 16 pixels in the halo
     static_assert(XP <= 36, "halo does not fit");
     extern __shared__ __attribute__((aligned(16))) char smem[];               // 2 stages
 
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
     const int Cs = first ? p.C1 : p.C2;
     const int cin0 = first ? c0 : c0 - p.C1;
     const int t_lo = split * p.tiles_per_split, t_hi = min(t_lo + p.tiles_per_split, p.ntiles);
-    const int tiles_img = (p.Hi * TW) >> 7;
+    const int tiles_img = TW == 8 ? 1 : (p.Hi * TW) >> 7;
 
     const __amdgpu_buffer_rsrc_t rDY = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.ntiles * 128 * p.ldy * 2, WG_SRD);
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? p.in1 : p.in2), 0, p.ntiles * 128 * Cs * 2, WG_SRD);
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
     // lane's column, swizzle and x-validity are fixed and a row is a scalar step.  NC strips x HR rows:
     //   TW=64: 9 x 4 — waves 0..7 take strips 0..7, waves 0..3 also row `wave` of strip 8;   TW=32: 5 x 6 — waves 0..4;
     //   TW=16: 3 x 10 — waves 0..5 as 3 strips x 2 groups of 5 rows.
-    constexpr int NC = HS / 8, RG = TW == 16 ? 2 : 1, RPG = HR / RG;
+    constexpr int NC = HS / 8, RG = TW <= 16 ? 2 : 1, RPG = HR / RG;
     const int strip = wave % (NC < 8 ? NC : 8), rgroup = wave / (NC < 8 ? NC : 8);
     const bool halo_wave = rgroup < RG;
     const int hy0 = rgroup * RPG;
@@ -459,8 +460,10 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
     {
         const int hx = strip * 8 + (lane >> 3), s = lane & 7;
         const int lslot = ((((s >> 1) ^ ((hx >> 1) & 3)) << 1) | (s & 1));       // HS % 8 == 0: the swizzle follows hx only
-        xv0 = ((hy0 - 1) * TW + hx - 1) * Cs * 2 + lslot * 16 + cin0 * 2;
-        xok0 = (unsigned)(hx - 1) < (unsigned)TW;
+        const int img = TW == 8 ? hx / 10 : 0;                                   // TW = 8: which of the tile's two images
+        const int x = TW == 8 ? hx - img * 10 - 1 : hx - 1;
+        xv0 = ((hy0 - 1) * TW + img * 64 + x) * Cs * 2 + lslot * 16 + cin0 * 2;
+        xok0 = (unsigned)x < (unsigned)TW && img < 2;
         if constexpr (TW == 64) {
             const int hx8 = 64 + (lane >> 3);
             xv8 = ((wave - 1) * TW + hx8 - 1) * Cs * 2 + lslot * 16 + cin0 * 2;      // row `wave` of strip 8 (64 % 8 == 0: same lslot)
@@ -496,13 +499,20 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
     };
 
     // ---- fragment read addresses
-    int addrA[4], addrB[3];
+    int addrA[4], addrB[3][2];                         // [kx][image of the tile (TW = 8 only)]
     {
         const int row = 4 * g + q;
 #pragma unroll
         for (int it = 0; it < 4; ++it) addrA[it] = row * 256 + (((wn * 4 + it) ^ (row & 7)) << 5) + 8 * pp;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) addrB[kx] = WGH_DY + (row + kx) * 128 + ((wc ^ (((row + kx) >> 1) & 3)) << 5) + 8 * pp;
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int im = 0; im < 2; ++im) {
+                // halo row of this lane's first pixel of a k-step: 32 consecutive pixels of an image row (TW >= 32), two rows
+                // (TW = 16), or four rows of one 8x8 image (TW = 8: pixel kp -> row kp >> 3, column kp & 7 of image `im`)
+                const int hp = TW == 8 ? (row >> 3) * HS + (row & 7) + im * 10 + kx : row + kx;
+                addrB[kx][im] = WGH_DY + hp * 128 + ((wc ^ ((hp >> 1) & 3)) << 5) + 8 * pp;
+            }
     }
     typedef __attribute__((address_space(3))) s16x4* lds_p;
     typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -535,12 +545,13 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int koffA = ks * 32 * 256;
-            const int koffB = (TW == 64 ? (ks >> 1) * HS + (ks & 1) * 32 : TW == 32 ? ks * HS : 2 * ks * HS) * 128;
+            const int koffB = (TW == 64 ? (ks >> 1) * HS + (ks & 1) * 32 : TW == 32 ? ks * HS : TW == 16 ? 2 * ks * HS : (ks & 1) * 4 * HS) * 128;
+            const int im = TW == 8 ? ks >> 1 : 0;
             bf16x8 fa[4], fb[9];
 #pragma unroll
             for (int it = 0; it < 4; ++it) fa[it] = tr_pair(sS + addrA[it] + koffA, 16 * 256);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) fb[t] = tr_pair(sS + addrB[t % 3] + koffB + ((t / 3) * HS) * 128, HI);
+            for (int t = 0; t < 9; ++t) fb[t] = tr_pair(sS + addrB[t % 3][im] + koffB + ((t / 3) * HS) * 128, HI);
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -698,8 +709,12 @@ bool wgrad_halo_plan(const DmWgrad* d, int64_t M, WgHP& hp) {
     if (!g_wgrad_halo || d->dtype != DM_BF16 || d->T != 9 || d->KW != 3 || d->sy != 1 || d->sx != 1) return false;
     if (d->ty != 1 || d->tx != 1 || d->oy0 != -1 || d->ox0 != -1) return false;
     if (d->Hq != d->Hi || d->Wq != d->Wi || d->Ho != d->Hq || d->Wo != d->Wq || d->osy != 1 || d->osx != 1 || d->ooy != 0 || d->oox != 0) return false;
-    if (d->Wi != 16 && d->Wi != 32 && d->Wi != 64) return false;
-    if ((d->Hi * d->Wi) % 128 != 0 || d->C1 % 64 != 0 || d->C2 % 64 != 0 || d->ldy % 8 != 0) return false;
+    if (d->Wi == 8) {                                                  // two whole 8x8 images per tile
+        if (d->Hi != 8 || d->B % 2 != 0) return false;
+    } else if ((d->Wi != 16 && d->Wi != 32 && d->Wi != 64) || (d->Hi * d->Wi) % 128 != 0) {
+        return false;
+    }
+    if (d->C1 % 64 != 0 || d->C2 % 64 != 0 || d->ldy % 8 != 0) return false;
     const int64_t cmax = d->C1 > d->C2 ? d->C1 : d->C2;
     if (M * cmax * 2 >= (1ll << 31) || M * d->ldy * 2 >= (1ll << 31)) return false;
     if (((uintptr_t)d->dy & 15) || ((uintptr_t)d->in1 & 15) || ((uintptr_t)d->in2 & 15)) return false;
@@ -745,7 +760,8 @@ extern "C" int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream) {
     if (wgrad_halo_plan(d, M, hp)) {
         if (d->Wi == 64) return launch_wgrad_halo<64>(hp, (hipStream_t)stream);
         if (d->Wi == 32) return launch_wgrad_halo<32>(hp, (hipStream_t)stream);
-        return launch_wgrad_halo<16>(hp, (hipStream_t)stream);
+        if (d->Wi == 16) return launch_wgrad_halo<16>(hp, (hipStream_t)stream);
+        return launch_wgrad_halo<8>(hp, (hipStream_t)stream);
     }
     WgP p;
     p.dy = (const char*)d->dy; p.in1 = (const char*)d->in1; p.in2 = (const char*)d->in2; p.dw = d->dw; p.dbias = d->dbias;
