@@ -525,7 +525,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
     const int m0 = mb * 256, n0 = nb * 128;
     const int C = p.C1 + p.C2;
     const int c_lo = split * p.kper;                       // this split's channel chunks [c_lo, nchunks)
-    const int nchunks = min(C >> 6, c_lo + p.kper);
+    const int nchunks = min((C + 63) >> 6, c_lo + p.kper);    // a lone partial chunk (C < 64, single source) reads zeros past C
     const int tiles_img = TW == 8 ? 1 : (p.Hi * TW) >> 8;
     const int b = TW == 8 ? mb * 4 : mb / tiles_img, y0 = TW == 8 ? 0 : (mb - b * tiles_img) * TH;
 
@@ -545,14 +545,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
         const int y = y0 + hy - 1, x = TW == 8 ? hx - img * 10 - 1 : hx - 1;
         const bool ok = (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)TW && img < 4;
         const int pix = ((b + img) * p.Hi + y) * TW + x;
-        hv1[i] = ok ? (unsigned)(pix * p.C1 * 2 + slotb) : OOB;
+        hv1[i] = ok && slotb < p.C1 * 2 ? (unsigned)(pix * p.C1 * 2 + slotb) : OOB;
         hv2[i] = ok ? (unsigned)(pix * p.C2 * 2 + slotb) : OOB;
     }
     unsigned wv[2];                                        // weight pieces 2 wave + j: 8 rows (n) x 128 B
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + (wave * 2 + j) * 8 + lrow;
-        wv[j] = n < p.N ? (unsigned)(n * p.ldw * 2 + slotb) : OOB;
+        wv[j] = n < p.N && slotb < C * 2 ? (unsigned)(n * p.ldw * 2 + slotb) : OOB;
     }
     int hoff[3][2][4];                                     // pixel-operand fragment addresses in the current halo buffer
 #pragma unroll
@@ -695,7 +695,7 @@ int launch_halo(const ConvP& p, hipStream_t st) {
     const int tiles = (p.M / 256) * cdiv(p.N, 128);
     ConvP q = p;
     // few tiles, deep K (the 8x8 / 16x16 layers): split the channel chunks over workgroups until the chip is full
-    const int nchunks = (p.C1 + p.C2) / 64;
+    const int nchunks = (p.C1 + p.C2 + 63) / 64;
     if (tiles <= 128 && nchunks >= 4 && dm_g_ws != nullptr) {
         int splits = 256 / tiles;
         if (splits > nchunks / 2) splits = nchunks / 2;
@@ -725,7 +725,8 @@ bool halo_eligible(const ConvP& p) {
     } else if ((p.Wi != 16 && p.Wi != 32 && p.Wi != 64) || (p.Hi * p.Wi) % 256 != 0) {
         return false;
     }
-    if (p.C1 % 64 != 0 || p.C2 % 64 != 0) return false;
+    // whole 64-channel chunks, or one partial chunk of a single source (the 8-channel stem / head gradients)
+    if ((p.C1 % 64 != 0 || p.C2 % 64 != 0) && !(p.C2 == 0 && p.C1 < 64)) return false;
     const int64_t pix = (int64_t)p.B * p.Hi * p.Wi;
     const int64_t cmax = p.C1 > p.C2 ? p.C1 : p.C2;
     return pix * cmax * 2 < (1ll << 31) && (int64_t)p.N * p.ldw * 2 < (1ll << 31);

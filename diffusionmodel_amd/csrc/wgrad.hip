@@ -463,11 +463,11 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
         const int img = TW == 8 ? hx / 10 : 0;                                   // TW = 8: which of the tile's two images
         const int x = TW == 8 ? hx - img * 10 - 1 : hx - 1;
         xv0 = ((hy0 - 1) * TW + img * 64 + x) * Cs * 2 + lslot * 16 + cin0 * 2;
-        xok0 = (unsigned)x < (unsigned)TW && img < 2;
+        xok0 = (unsigned)x < (unsigned)TW && img < 2 && lslot * 8 < Cs;      // (a lone partial chunk, C < 64, reads zeros past C)
         if constexpr (TW == 64) {
             const int hx8 = 64 + (lane >> 3);
             xv8 = ((wave - 1) * TW + hx8 - 1) * Cs * 2 + lslot * 16 + cin0 * 2;      // row `wave` of strip 8 (64 % 8 == 0: same lslot)
-            xok8 = hx8 - 1 < TW;
+            xok8 = hx8 - 1 < TW && lslot * 8 < Cs;
         }
     }
     auto issue = [&](int stage, int tile) {
@@ -582,7 +582,8 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
                 if (n >= p.N) continue;
                 float* row = p.dw + (size_t)n * p.ldw + c0 + wc * 16 + il;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) row[t * C] += acc[it][t][r];
+                for (int t = 0; t < 9; ++t)
+                    if (c0 + wc * 16 + il < C) row[t * C] += acc[it][t][r];
             }
     } else {                                     // register image as it stands: 1 KiB contiguous per wave-instruction
         f32x4* dst = (f32x4*)p.ws + ((((size_t)split * p.blocks + block) * 8 + wave) * 36) * 64 + lane;
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restri
     float* o = dw + (size_t)n * ldw + t * C + chunk * 64 + (wave >> 1) * 16 + (lane & 15);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        if (n + r < N) o[(size_t)r * ldw] += s[r];
+        if (n + r < N && chunk * 64 + (wave >> 1) * 16 + (lane & 15) < C) o[(size_t)r * ldw] += s[r];
 }
 
 int g_wgrad_halo = 1;
@@ -714,7 +715,8 @@ bool wgrad_halo_plan(const DmWgrad* d, int64_t M, WgHP& hp) {
     } else if ((d->Wi != 16 && d->Wi != 32 && d->Wi != 64) || (d->Hi * d->Wi) % 128 != 0) {
         return false;
     }
-    if (d->C1 % 64 != 0 || d->C2 % 64 != 0 || d->ldy % 8 != 0) return false;
+    if (d->ldy % 8 != 0) return false;
+    if ((d->C1 % 64 != 0 || d->C2 % 64 != 0) && !(d->C2 == 0 && d->C1 < 64)) return false;     // whole chunks, or one partial chunk
     const int64_t cmax = d->C1 > d->C2 ? d->C1 : d->C2;
     if (M * cmax * 2 >= (1ll << 31) || M * d->ldy * 2 >= (1ll << 31)) return false;
     if (((uintptr_t)d->dy & 15) || ((uintptr_t)d->in1 & 15) || ((uintptr_t)d->in2 & 15)) return false;
@@ -722,7 +724,7 @@ bool wgrad_halo_plan(const DmWgrad* d, int64_t M, WgHP& hp) {
     hp.dy = (const char*)d->dy; hp.in1 = (const char*)d->in1; hp.in2 = (const char*)d->in2; hp.dw = d->dw; hp.dbias = d->dbias; hp.ws = dm_g_ws;
     hp.B = d->B; hp.Hi = d->Hi; hp.C1 = d->C1; hp.C2 = d->C2; hp.N = d->N; hp.ldy = d->ldy; hp.ldw = d->ldw;
     hp.ntiles = (int)(M / 128);
-    hp.nchunks = C / 64;
+    hp.nchunks = (C + 63) / 64;
     hp.blocks = cdiv(d->N, 128) * hp.nchunks;
     int splits = 256 / hp.blocks;
     if (splits < 1) splits = 1;

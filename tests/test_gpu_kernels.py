@@ -123,6 +123,8 @@ HALO_CASES = [
     (3, 192, 0, 136, 32),    # three chunks, ragged N, odd batch
     (4, 64, 0, 128, 8),      # 8x8 images: four whole images side by side in one halo
     (8, 128, 64, 192, 8),    # 8x8, two tiles, concatenated sources, two n-tiles
+    (2, 8, 0, 128, 32),      # one partial chunk (the 8-channel stem / head-gradient layers)
+    (4, 8, 0, 24, 16),       # partial chunk and partial n tile
 ]
 
 
