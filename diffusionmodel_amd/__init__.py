@@ -10,6 +10,7 @@ from .ddpm import DDPM, SCHEDULE_KEYS, ddpm_schedules  # noqa: F401
 from .modules import (ContextUnet, CoordAttn, EmbedFC, LocalEnhancer, ResConvBlock, ResidualConvBlock, SEBlock,  # noqa: F401
                       UnetDown, UnetUp)
 from .optim import FusedAdamW  # noqa: F401
+from .graph import GraphedTrainStep  # noqa: F401
 
-__all__ = ["Cfg", "Config", "ContextUnet", "CoordAttn", "DDPM", "DmError", "EmbedFC", "FusedAdamW", "LocalEnhancer",
+__all__ = ["Cfg", "Config", "ContextUnet", "CoordAttn", "DDPM", "DmError", "EmbedFC", "FusedAdamW", "GraphedTrainStep", "LocalEnhancer",
            "ResConvBlock", "ResidualConvBlock", "SEBlock", "UnetDown", "UnetUp", "ddpm_schedules"]

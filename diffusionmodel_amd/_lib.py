@@ -87,7 +87,8 @@ _PROTOS = {
     "dm_fill_t": [vp, vp, i32, i32],
     "dm_randn": [vp, i64, u64, u64],
     "dm_sumsq": [vp, i64, vp],
-    "dm_adamw": [vp, vp, vp, vp, i64, vp, vp, vp],
+    "dm_adamw": [vp, vp, vp, vp, i64, vp, vp, vp, vp],
+    "dm_randn_dev": [vp, i64, u64, vp],
     "dm_pack_multi": [vp, vp, vp, i32],
 }
 _NO_STREAM = {"dm_set_workspace": ([vp, i64], i32), "dm_set_conv_variant": ([i32], i32), "dm_set_wgrad_variant": ([i32], i32), "dm_version": ([], i32), "dm_last_error": ([], C.c_char_p), "dm_colstat_blocks": ([i32], i32)}

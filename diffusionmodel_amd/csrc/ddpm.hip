@@ -34,7 +34,8 @@ __device__ inline void normal4(uint64_t seed, uint64_t ctr_hi, uint64_t ctr_lo, 
     box_muller(r.z, r.w, z[2], z[3]);
 }
 
-__global__ void randn_kernel(float* out, int64_t n, uint64_t seed, uint64_t offset) {
+__global__ void randn_kernel(float* out, int64_t n, uint64_t seed, uint64_t offset, const uint64_t* offset_dev) {
+    if (offset_dev) offset = *offset_dev;              // stream offset kept on the device (hipGraph replays advance it)
     const int64_t n4 = (n + 3) / 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float z[4];
@@ -170,8 +171,14 @@ __global__ void sumsq_kernel(const float* g, int64_t n, float* out) {
 // 4 parameters per lane-iteration (16-byte loads / stores of p, g, m, v: 28 B of traffic per parameter, HBM-bound);
 // optionally refreshes the bf16 shadow of the parameters that the conv kernels read (p16[i] = bf16(p[i])).
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hy,
-                                                    bf16* p16) {
-    const float lr = hy[0], b1 = hy[1], b2 = hy[2], eps = hy[3], wd = hy[4], max_norm = hy[5], gscale = hy[6], bc1 = hy[7], bc2 = hy[8];
+                                                    bf16* p16, const int64_t* step_dev) {
+    const float lr = hy[0], b1 = hy[1], b2 = hy[2], eps = hy[3], wd = hy[4], max_norm = hy[5], gscale = hy[6];
+    float bc1 = hy[7], bc2 = hy[8];
+    if (step_dev) {                                    // step count kept on the device (hipGraph replays advance it)
+        const double t = (double)*step_dev;
+        bc1 = (float)(1.0 - pow((double)b1, t));
+        bc2 = (float)(1.0 - pow((double)b2, t));
+    }
     float coef = gscale;
     if (max_norm > 0.f) {
         const float total = sqrtf(sumsq[0]) * gscale;
@@ -215,7 +222,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
 
 extern "C" int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, dm_stream_t s) {
     DM_CHECK_ARG(out && n > 0, "dm_randn: bad arguments");
-    hipLaunchKernelGGL(randn_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, ST, out, n, seed, offset);
+    hipLaunchKernelGGL(randn_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, ST, out, n, seed, offset, (const uint64_t*)nullptr);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_randn_dev(float* out, int64_t n, uint64_t seed, const uint64_t* offset_dev, dm_stream_t s) {
+    DM_CHECK_ARG(out && n > 0 && offset_dev, "dm_randn_dev: bad arguments");
+    hipLaunchKernelGGL(randn_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, ST, out, n, seed, (uint64_t)0, offset_dev);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
@@ -269,14 +283,14 @@ extern "C" int dm_sumsq(const float* g, int64_t n, float* out, dm_stream_t s) {
 }
 
 extern "C" int dm_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hyper9, void* p_bf16,
-                        dm_stream_t s) {
+                        const int64_t* step_dev, dm_stream_t s) {
     DM_CHECK_ARG(p && g && m && v && sumsq && hyper9 && n > 0, "dm_adamw: bad arguments");
     DM_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && ((uintptr_t)p_bf16 & 7) == 0,
                  "dm_adamw: the flat buffers must be 16-byte aligned (the bf16 shadow 8-byte)");
     static int blocks_env = -1;
     if (blocks_env < 0) { const char* e = getenv("DM_ADAMW_BLOCKS"); blocks_env = e ? atoi(e) : 0; }
-    const int blocks = blocks_env > 0 ? blocks_env : grid_for(n / 4 + 1, 256, 4096);
-    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, ST, p, g, m, v, n, sumsq, hyper9, (bf16*)p_bf16);
+    const int blocks = blocks_env > 0 ? blocks_env : grid_for(n / 4 + 1, 256, 16384);
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, ST, p, g, m, v, n, sumsq, hyper9, (bf16*)p_bf16, step_dev);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

@@ -131,8 +131,12 @@ class DDPM(_DDPM):
         if ts is None:
             ts = torch.randint(1, self.n_T + 1, (B,), device=dev)
         if noise is None:
+            # the stream offset lives on the device (and is advanced there) so that a captured train step draws fresh noise
             self._rng_calls += 1
-            noise = ops.randn(tuple(x.shape), dev, self._seed(), self._rng_calls)
+            if getattr(self, "_rng_dev", None) is None or self._rng_dev.device != dev:
+                self._rng_dev = torch.full((1,), self._rng_calls - 1, dtype=torch.int64, device=dev)
+            self._rng_dev.add_(1)
+            noise = ops.randn(tuple(x.shape), dev, self._seed(), self._rng_dev)
         if context_mask is None:
             context_mask = torch.bernoulli(torch.full((B,), float(self.drop_prob), device=dev))
         ts = ts.to(dev).long()

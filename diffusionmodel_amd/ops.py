@@ -996,8 +996,12 @@ def fill_t(t, step, n_T):
 
 
 def randn(shape, device, seed, offset):
+    """Philox N(0,1); `offset` is a Python int, or a device int64 tensor that is read when the kernel runs."""
     out = torch.empty(shape, dtype=torch.float32, device=device)
-    call("dm_randn", ptr(out), out.numel(), int(seed), int(offset))
+    if isinstance(offset, torch.Tensor):
+        call("dm_randn_dev", ptr(out), out.numel(), int(seed), ptr(offset))
+    else:
+        call("dm_randn", ptr(out), out.numel(), int(seed), int(offset))
     return out
 
 

@@ -60,6 +60,9 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._slots.append((p, off, n))
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._hyper = torch.zeros(9, dtype=torch.float32, device=dev)
+        self._hyper_host = None                       # last values uploaded: re-sent only when a hyper-parameter changes
+        self._table = None                            # (pinned host, device) pointer table of gather_grads
+        self._step_dev = torch.zeros(1, dtype=torch.int64, device=dev)   # step count on the device (bias corrections)
         self.refresh_shadow()
         ops.bump_weight_epoch()
         ops.ARENA_ENABLED[0] = True                  # step() recycles the gradient scratch arena
@@ -95,9 +98,25 @@ class FusedAdamW(torch.optim.Optimizer):
             for lo in range(0, n, self.CHUNK):       # one workgroup per <= CHUNK elements
                 rows.append((g.data_ptr() + 4 * lo, base + 4 * (off + lo), min(self.CHUNK, n - lo)))
         if rows:
-            table = torch.tensor(rows, dtype=torch.int64).to(self.flat_g.device, non_blocking=True)
+            # pointer table: pinned host buffers (so the upload is a plain async copy, legal in a stream capture), a ring of
+            # four guarded by events because the host runs ahead of the device in eager mode
+            if self._table is None or self._table[0][0].shape[0] < len(rows):
+                cap = max(2 * len(rows), 1024)
+                self._table = [[torch.empty((cap, 3), dtype=torch.int64).pin_memory(),
+                                torch.empty((cap, 3), dtype=torch.int64, device=self.flat_g.device), None] for _ in range(4)]
+                self._table_i = 0
+            capturing = torch.cuda.is_current_stream_capturing()
+            slot = self._table[self._table_i]
+            self._table_i = (self._table_i + 1) % 4
+            if slot[2] is not None and not capturing:
+                slot[2].synchronize()                 # the copy that last read this host buffer has run
+            host, table = slot[0], slot[1]
+            host[:len(rows)] = torch.tensor(rows, dtype=torch.int64)
+            table[:len(rows)].copy_(host[:len(rows)], non_blocking=True)
+            if not capturing:
+                slot[2] = torch.cuda.Event()
+                slot[2].record()
             call("dm_scatter_copy", ptr(table), len(rows), 1)
-            self._table = table
         for p, _, _ in self._slots:
             p.grad = None
         ops.ZERO_ARENA.recycle()                     # every small gradient accumulator has been copied out: one fill re-zeroes them
@@ -110,15 +129,25 @@ class FusedAdamW(torch.optim.Optimizer):
         g0 = self.param_groups[0]
         b1, b2 = g0["betas"]
         self._step += 1
-        hyper = [g0["lr"], b1, b2, g0["eps"], g0["weight_decay"], self.max_grad_norm, self.grad_scale,
-                 1.0 - b1 ** self._step, 1.0 - b2 ** self._step]
-        self._hyper.copy_(torch.tensor(hyper, dtype=torch.float32), non_blocking=True)
+        self.sync_hyper()
+        self._step_dev.add_(1)                       # the kernel derives 1 - beta^t from the device-side count
         self._sumsq.zero_()
         call("dm_sumsq", ptr(self.flat_g), self.total, ptr(self._sumsq))
         call("dm_adamw", ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.total,
-             ptr(self._sumsq), ptr(self._hyper), ptr(self.flat_p16))
+             ptr(self._sumsq), ptr(self._hyper), ptr(self.flat_p16), ptr(self._step_dev))
         ops.bump_weight_epoch()
         ops.refresh_packs()                          # every transposed (input-gradient) weight pack, one launch
+
+    def sync_hyper(self):
+        """Upload lr / betas / eps / weight decay / clip norm when they differ from the device copy (lr schedules)."""
+        g0 = self.param_groups[0]
+        b1, b2 = g0["betas"]
+        hyper = [g0["lr"], b1, b2, g0["eps"], g0["weight_decay"], self.max_grad_norm, self.grad_scale, 0.0, 0.0]
+        if hyper != self._hyper_host:
+            if torch.cuda.is_current_stream_capturing():
+                raise DmError("FusedAdamW: a hyper-parameter changed inside a stream capture; change it between replays")
+            self._hyper.copy_(torch.tensor(hyper, dtype=torch.float32))
+            self._hyper_host = hyper
 
     def grad_norm(self):
         """Global gradient norm of the last step (device tensor, no host sync)."""

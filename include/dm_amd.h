@@ -226,6 +226,8 @@ int dm_cfg_update(float* x, const float* eps2n, const float* z, float guide_w, c
 int dm_fill_t(float* t, const int32_t* step, int n_T, int B, dm_stream_t s);
 /* N(0,1) fill by Philox4x32-10 (used for noise when the caller does not inject it) */
 int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, dm_stream_t s);
+/* same stream, the offset read from device memory at execution time (a captured hipGraph draws fresh noise every replay) */
+int dm_randn_dev(float* out, int64_t n, uint64_t seed, const uint64_t* offset_dev, dm_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser: clip_grad_norm_(1.0) + AdamW (new_scripy.py:715-719, 798, 801) on flat fp32 buffers.
@@ -234,8 +236,11 @@ int dm_sumsq(const float* g, int64_t n, float* out /* one float, += */, dm_strea
 /* clip coefficient = min(1, max_norm/(sqrt(*sumsq)*gscale + 1e-6)); gscale folds 1/world etc.
  * hyper = {lr, beta1, beta2, eps, weight_decay, max_norm, gscale, bias_corr1, bias_corr2} (device) */
 /* p_bf16 (may be NULL): bf16 shadow of the parameters, refreshed in the same pass (p_bf16[i] = bf16(p[i])) — the conv
- * kernels read it as their packed forward weights, so no per-layer cast launch follows an optimiser step */
-int dm_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hyper9, void* p_bf16, dm_stream_t s);
+ * kernels read it as their packed forward weights, so no per-layer cast launch follows an optimiser step;
+ * step_dev (may be NULL): device-resident step count t; when given, the bias corrections 1 - beta^t are computed in the
+ * kernel and hyper9[7..8] are ignored (lets a captured hipGraph of the train step be replayed) */
+int dm_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hyper9, void* p_bf16,
+             const int64_t* step_dev, dm_stream_t s);
 
 /* Evaluation helpers of the drivers (new_scripy.py:1188-1250): per image pair (a_i, b_i), n_per_image floats each,
  * out[i] = {sum a, sum b, sum a^2, sum b^2, sum ab, min a, min b, n} as 8 doubles — global-statistics SSIM and PSNR

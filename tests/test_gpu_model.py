@@ -380,3 +380,61 @@ def test_full_size_properties_cfg2():
 def math_isfinite(v):
     import math
     return math.isfinite(v)
+
+
+def test_graphed_train_step_matches_eager_and_leaves_state_alone():
+    """GraphedTrainStep: (1) warm-up + capture must not change weights, optimiser moments, BatchNorm buffers or RNG
+    counters; (2) replays must train exactly like eager steps.  n_T = 1 and drop_prob = 0 make the torch-RNG draws
+    (timesteps, context mask) deterministic, the DDPM noise comes from the Philox kernel's device-side offset in
+    both modes, so the two trajectories differ only by fp32 atomic ordering in the small weight-gradient launches."""
+    import diffusionmodel_amd as D
+
+    def make():
+        torch.manual_seed(7)
+        net = D.ContextUnet(3, 32, 4, bottleneck_k=4, dtype=torch.float32)
+        ddpm = D.DDPM(net, (1e-4, 0.02), 1, DEV, drop_prob=0.0)
+        ddpm.train()
+        ddpm.rng_seed = 99
+        opt = D.FusedAdamW(ddpm.parameters(), lr=1e-3, weight_decay=1e-5, max_grad_norm=1.0)
+        return ddpm, opt
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 64, 64, generator=g).to(DEV)
+    c = torch.randint(0, 4, (2,), generator=g).to(DEV)
+    am = torch.ones(2, 64, 64).to(DEV)
+
+    da, oa = make()
+    losses_a = []
+    for _ in range(3):
+        oa.zero_grad()
+        loss = da(x, c, am)
+        loss.backward()
+        oa.step()
+        losses_a.append(loss.item())
+
+    db, ob = make()
+    p0, m0 = ob.flat_p.clone(), ob.exp_avg.clone()
+    bufs0 = [b.clone() for b in db.buffers()]
+    step = D.GraphedTrainStep(db, ob, x, c, am)
+    assert torch.equal(ob.flat_p, p0) and torch.equal(ob.exp_avg, m0) and ob._step == 0 and int(ob._step_dev.item()) == 0
+    assert all(torch.equal(b, b0) for b, b0 in zip(db.buffers(), bufs0))
+    assert db._rng_calls == 0 and int(db._rng_dev.item()) == 0
+    losses_b = [step(x, c, am).item() for _ in range(3)]
+    assert ob._step == 3 and int(ob._step_dev.item()) == 3 and int(db._rng_dev.item()) == 3
+    for la, lb in zip(losses_a, losses_b):
+        assert abs(la - lb) <= 2e-4 * max(abs(la), 1e-3), (losses_a, losses_b)
+    assert losses_b[-1] < losses_b[0]
+    # Adam turns noise-level gradients (conv biases in front of train-mode BatchNorm are mathematically zero) into +-lr moves
+    # whose sign follows the fp32 atomic order, so the weights agree to a few lr, not to rounding
+    rel = ((oa.flat_p - ob.flat_p).norm() / oa.flat_p.norm()).item()
+    assert rel < 5e-3, rel
+    # BatchNorm bookkeeping of the replays reaches the state dict
+    nbt_a = [v for k, v in da.state_dict().items() if k.endswith("num_batches_tracked")]
+    nbt_b = [v for k, v in db.state_dict().items() if k.endswith("num_batches_tracked")]
+    assert nbt_a and all(int(a) == int(b) for a, b in zip(nbt_a, nbt_b))
+    # an eager step after the replays still works (packs are rebuilt lazily)
+    ob.zero_grad()
+    loss = db(x, c, am)
+    loss.backward()
+    ob.step()
+    assert torch.isfinite(loss).item()
