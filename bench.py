@@ -206,7 +206,7 @@ def main():
     traffic, traffic_src = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
-            pmc = json.load(f)["kernels"].get("conv_igemm2<bf16>" if dtype == torch.bfloat16 else "", None)
+            pmc = json.load(f)["kernels"].get("conv3x3_halo<bf16>" if dtype == torch.bfloat16 else "", None)
         if pmc and args.n_feat == 128 and args.size == 64 and args.batch == 64:
             traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)"
     except (OSError, KeyError, ValueError):
@@ -214,7 +214,8 @@ def main():
     roofline = {"bound": "mfma", "kernel": "dm_conv<%s> launches, fwd + dgrad (conv3x3_halo_kernel on the 3x3 layers, conv_igemm2_kernel elsewhere)" % args.dtype,
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (avg)", "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": "A read once + weights + output written once = 67-201 MB on the 64^2 layers",
+                "traffic_kernel": "conv3x3_halo_kernel (3/4 of the dm_conv bf16 time)",
+                "algorithmic_bytes_per_launch": "input read once + weights + output written once = 67-201 MB on the 64^2 layers, 34-50 MB on 32^2..8^2",
                 "launches": fl[dom][2], "avg_launch_us": round(fl[dom][1] / max(fl[dom][2], 1) * 1e6, 2),
                 "algorithmic_tflop_per_step": round(fl[dom][0] / prof_steps / 1e12, 4),
                 "wgrad": {"achieved": round(fl["conv_wgrad"][0] / max(fl["conv_wgrad"][1], 1e-12) / 1e12, 2),
