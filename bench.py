@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
     ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=8)
     ap.add_argument("--cpu-iters", dest="cpu_iters", type=int, default=2)
-    ap.add_argument("--buckets", type=int, default=4)
+    ap.add_argument("--buckets", type=int, default=6)
     ap.add_argument("--graph", dest="graph", action="store_true",
                     help="replay the train step as one captured hipGraph (host enqueue 3 ms instead of 16 ms per step; the device-side "
                          "time is the same, so the default stays eager, which also keeps the per-launch events simple)")
@@ -127,7 +127,8 @@ def main():
     ddpm.train()
     opt = D.FusedAdamW(ddpm.parameters(), lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, grad_scale=1.0 / world)
     use_dp = world > 1 or args.force_dp
-    reducer = parallel.GradReducer(opt.flat_g, n_buckets=args.buckets) if use_dp else None
+    # bucketed all-reduce of the flat gradient buffer, each bucket launched as soon as the backward pass has written it
+    reducer = parallel.OverlappedGradReducer(opt, n_buckets=args.buckets) if use_dp else None
     if use_dp:
         parallel.broadcast_parameters(opt.flat_p)
         opt.refresh_shadow()                   # the masters changed outside step(): redo their bf16 shadow
@@ -145,10 +146,12 @@ def main():
         if graphed is not None and not eager:
             return graphed()
         opt.zero_grad()
+        if reducer is not None:
+            reducer.begin()
         loss = ddpm(x, c, am)
         loss.backward()
         if reducer is not None:
-            reducer.all_reduce()
+            reducer.finish()
         opt.step()
         return loss
 

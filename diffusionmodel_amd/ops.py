@@ -23,6 +23,7 @@ from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, call, dt, ptr
 BN_EPS = 1e-5
 _EPOCH = [0]          # bumped by the fused optimiser: invalidates packed-weight caches
 _CACHE = {}
+ON_WGRAD = None       # parallel.GradReducer: called with the parameter whose main_grad a weight-gradient launch just completed
 PROFILE = None        # bench.py sets this to a list to collect (kind, flops, start_event, end_event, shape)
 
 
@@ -434,11 +435,15 @@ class ConvBnAct(torch.autograd.Function):
                     tgt = _zeros((N, kh, kw, Cin), torch.float32, g)
                 _wgrad_call(dz, x, x2, tgt, db, **wg_geom)
                 dw = None if main is not None else tgt.permute(0, 3, 1, 2)
+                if main is not None and ON_WGRAD is not None:
+                    ON_WGRAD(w)
             else:
                 tmp = _zeros((N, T, Cp), torch.float32, g)
                 _wgrad_call(dz, x, x2, tmp, db, **wg_geom)
                 if main is not None:
                     call("dm_unpad_dw", ptr(tmp), ptr(main), N, T, Cin, Cp, 1)
+                    if ON_WGRAD is not None:
+                        ON_WGRAD(w)
                 else:
                     tgt = _empty((N, kh, kw, Cin), torch.float32, g)
                     call("dm_unpad_dw", ptr(tmp), ptr(tgt), N, T, Cin, Cp, 0)
@@ -520,6 +525,8 @@ class ConvTransposeKS(torch.autograd.Function):
             _wgrad_call(xin, g, None, tgt, None, dtype=dtype, B=B, Hi=h * k, Wi=wd * k, C1=Cout, C2=0, Hq=h, Wq=wd, sy=k, sx=k, T=T, KW=k,
                         ty=1, tx=1, oy0=0, ox0=0, Ho=h, Wo=wd, N=Cin, ldy=Cin, ldw=T * Cout)
             dw = None if main is not None else tgt.permute(0, 3, 1, 2)
+            if main is not None and ON_WGRAD is not None:
+                ON_WGRAD(w)
             # bias gradient: column sums of g over all pixels
             M = B * h * k * wd * k
             nblk = L.colstat_blocks(M)

@@ -85,6 +85,133 @@ class GradReducer:
         self.finish()
 
 
+class OverlappedGradReducer:
+    """Gradient all-reduce overlapped with the backward pass.
+
+    The conv weight-gradient kernels write straight into the optimiser's flat gradient buffer (`param.main_grad`) and
+    account for ~99 % of its bytes; the backward pass completes them back to front.  The buffer is cut into buckets on
+    parameter boundaries; `ops.ON_WGRAD` tells the reducer when a parameter's weight gradient has been launched, and as
+    soon as the last main-grad parameter of a bucket is in, the bucket's all-reduce starts on a side stream (ordered after
+    the launch stream by an event) while the backward pass goes on.  The remaining parameters (biases, BatchNorm, dense
+    layers: autograd `.grad` tensors that the optimiser folds in after backward) sit at zero in those early reductions;
+    they are packed into one small contiguous buffer after backward, reduced once, and scattered back.
+
+        red = OverlappedGradReducer(opt)          # after FusedAdamW, before the first step
+        opt.zero_grad(); red.begin(); loss.backward(); red.finish(); opt.step()
+
+    One all-reduce per bucket per step: no gradient accumulation over several backward passes in this mode."""
+
+    def __init__(self, opt, n_buckets=6, group=None):
+        from . import ops
+        self.opt, self.group, self._ops = opt, group, ops
+        self.flat = opt.flat_g
+        self.active = dist.is_initialized()
+        self._stream = torch.cuda.Stream() if self.flat.is_cuda else None
+        slots = opt._slots                                        # (param, offset, numel) in flat-buffer order
+        main = [(i, p, off, n) for i, (p, off, n) in enumerate(slots) if hasattr(p, "main_grad")]
+        total_main = sum(n for _, _, _, n in main)
+        # bucket boundaries on parameter boundaries, ~equal main-grad bytes each
+        self.buckets, lo_slot, acc = [], 0, 0
+        target = max(1, total_main // max(1, n_buckets))
+        for i, (p, off, n) in enumerate(slots):
+            if hasattr(p, "main_grad"):
+                acc += n
+            last = i == len(slots) - 1
+            if (acc >= target and len(self.buckets) < n_buckets - 1) or last:
+                lo = slots[lo_slot][1]
+                hi = off + (n + 3) // 4 * 4 if not last else self.flat.numel()
+                self.buckets.append({"lo": lo, "hi": hi, "slots": range(lo_slot, i + 1)})
+                lo_slot, acc = i + 1, 0
+        self._bucket_of, self._need = {}, []
+        for b, bk in enumerate(self.buckets):
+            ids = [id(slots[i][0]) for i in bk["slots"] if hasattr(slots[i][0], "main_grad")]
+            for k in ids:
+                self._bucket_of[k] = b
+            self._need.append(len(ids))
+        # everything that is not a main-grad weight: packed into one contiguous buffer for a single late all-reduce
+        self._small = [(off, n) for (p, off, n) in slots if not hasattr(p, "main_grad")]
+        self._small_total = sum((n + 3) // 4 * 4 for _, n in self._small)
+        self._packed = torch.zeros(max(self._small_total, 4), dtype=torch.float32, device=self.flat.device)
+        self._tables = None
+        self._pending, self._launched, self._works = [], [], []
+
+    # ---- per step ----------------------------------------------------------------------------
+    def begin(self):
+        self._pending = list(self._need)
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+        self._ops.ON_WGRAD = self._notify if self.active else None
+
+    def _notify(self, p):
+        b = self._bucket_of.get(id(p))
+        if b is None or self._launched[b]:
+            return
+        self._pending[b] -= 1
+        if self._pending[b] <= 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        self._launched[b] = True
+        bk = self.buckets[b]
+        view = self.flat[bk["lo"]:bk["hi"]]
+        if self._stream is not None:
+            self._stream.wait_stream(torch.cuda.current_stream())          # the weight gradients launched so far
+            with torch.cuda.stream(self._stream):
+                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _copy_small(self, to_packed):
+        """flat <-> packed for the small parameters, one multi-tensor launch (CPU tensors: plain slicing)."""
+        if not self.flat.is_cuda:
+            o = 0
+            for off, n in self._small:
+                if to_packed:
+                    self._packed[o:o + n] = self.flat[off:off + n]
+                else:
+                    self.flat[off:off + n] = self._packed[o:o + n]
+                o += (n + 3) // 4 * 4
+            return
+        from ._lib import call, ptr
+        if self._tables is None:
+            rows_in, rows_out, o = [], [], 0
+            fb, pb = self.flat.data_ptr(), self._packed.data_ptr()
+            for off, n in self._small:
+                for lo in range(0, n, 16384):
+                    m = min(16384, n - lo)
+                    rows_in.append((fb + 4 * (off + lo), pb + 4 * (o + lo), m))
+                    rows_out.append((pb + 4 * (o + lo), fb + 4 * (off + lo), m))
+                o += (n + 3) // 4 * 4
+            dev = self.flat.device
+            self._tables = (torch.tensor(rows_in, dtype=torch.int64).to(dev), torch.tensor(rows_out, dtype=torch.int64).to(dev), len(rows_in))
+        tin, tout, n_rows = self._tables
+        call("dm_scatter_copy", ptr(tin if to_packed else tout), n_rows, 0)
+
+    def finish(self):
+        """Call after backward: reduces what is left (buckets nobody completed, the small parameters) and makes the summed
+        gradients visible to the launch stream.  Folds the autograd `.grad` tensors into the flat buffer on the way."""
+        self._ops.ON_WGRAD = None
+        if not self.active:
+            return
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self._launch(b)
+        # the early reductions summed zeros in the small slots; nothing else may touch those slots until they are done
+        for w in self._works:
+            w.wait()
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+        self._works = []
+        self.opt.gather_grads()                       # local small gradients into their (still local) slots
+        if self._small_total:
+            self._copy_small(True)
+            dist.all_reduce(self._packed, op=dist.ReduceOp.SUM, group=self.group)
+            self._copy_small(False)
+
+    def all_reduce(self):                             # drop-in for GradReducer when nothing was overlapped
+        self.finish()
+
+
 def broadcast_parameters(flat_params, src=0, group=None):
     """Identical initial weights on every rank."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -159,3 +159,66 @@ def test_gloo_data_parallel_matches_accumulation(tmp_path):
     flat_acc = torch.cat([v.grad.reshape(-1) for v in P.values() if v.requires_grad])
     assert flat_dp.shape == flat_acc.shape
     assert torch.allclose(flat_dp, flat_acc, rtol=1e-5, atol=1e-7), (flat_dp - flat_acc).abs().max()
+
+
+# ---- overlapped reducer: bucket launches driven by weight-gradient notifications, small parameters in one late reduce ----
+class _FakeParam:
+    def __init__(self, n, main):
+        self.n = n
+        if main:
+            self.main_grad = None            # attribute presence = "the wgrad kernel writes the flat buffer directly"
+
+
+class _FakeOpt:
+    """The three things OverlappedGradReducer uses of FusedAdamW: flat_g, _slots, gather_grads()."""
+
+    def __init__(self, sizes_main):
+        self._slots, off = [], 0
+        for n, main in sizes_main:
+            self._slots.append((_FakeParam(n, main), off, n))
+            off += (n + 3) // 4 * 4
+        self.flat_g = torch.zeros(off)
+        self.small_local = {}
+
+    def gather_grads(self):
+        for (p, off, n) in self._slots:
+            if id(p) in self.small_local:
+                self.flat_g[off:off + n] += self.small_local.pop(id(p))
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from diffusionmodel_amd import ops
+    parallel.init_from_env("gloo")
+    layout = [(37, True), (5, False), (1000, True), (8, False), (8, False), (513, True), (3, False), (2048, True), (64, False), (700, True)]
+    opt = _FakeOpt(layout)
+    red = parallel.OverlappedGradReducer(opt, n_buckets=3)
+    g = torch.Generator().manual_seed(100 + rank)
+    expect_local = torch.zeros_like(opt.flat_g)
+    for step in range(2):                                        # two steps: per-step state must reset
+        opt.flat_g.zero_()
+        expect_local.zero_()
+        red.begin()
+        for (p, off, n) in reversed(opt._slots):                 # "backward": last layer first
+            v = torch.randn(n, generator=g)
+            expect_local[off:off + n] = v
+            if hasattr(p, "main_grad"):
+                opt.flat_g[off:off + n] = v                      # what the weight-gradient kernel does
+                ops.ON_WGRAD(p)
+            else:
+                opt.small_local[id(p)] = v                       # autograd .grad, folded in by gather_grads()
+        red.finish()
+        assert ops.ON_WGRAD is None
+    torch.save((opt.flat_g.clone(), expect_local), os.path.join(out_dir, f"ov_{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_overlapped_reducer_equals_plain_sum(tmp_path):
+    import torch.multiprocessing as mp
+    world, port = 2, 31000 + os.getpid() % 2000
+    mp.spawn(_overlap_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got0, loc0 = torch.load(os.path.join(str(tmp_path), "ov_0.pt"))
+    got1, loc1 = torch.load(os.path.join(str(tmp_path), "ov_1.pt"))
+    assert torch.equal(got0, got1)
+    assert torch.allclose(got0, loc0 + loc1, rtol=0, atol=1e-6)
