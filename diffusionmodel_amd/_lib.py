@@ -43,6 +43,7 @@ _PROTOS = {
     "dm_bn_act_fwd": [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32],
     "dm_bn_act_bwd_reduce": [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp],
     "dm_col_reduce": [vp, i32, i32, vp, i32],
+    "dm_col_reduce2": [vp, vp, i32, i32, vp, vp],
     "dm_bn_act_bwd_apply": [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp],
     "dm_bn_fold": [vp, vp, vp, vp, vp, f32, i32, vp, vp],
     "dm_gn_act_fwd": [vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp],

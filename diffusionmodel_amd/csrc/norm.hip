@@ -147,6 +147,21 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* part, int 
     if (lane == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
+// two partial arrays of the same shape in one launch (dbeta / dgamma of a BatchNorm backward)
+__global__ __launch_bounds__(256) void col_reduce2_kernel(const float* part1, const float* part2, int nblk, int C, float* out1, float* out2) {
+    int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= 2 * C) return;
+    const float* part = c < C ? part1 : part2;
+    float* out = c < C ? out1 : out2;
+    if (c >= C) c -= C;
+    double s = 0.0;
+    for (int b = lane; b < nblk; b += 64) s += (double)part[(size_t)b * C + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) out[c] = (float)s;
+}
+
 // Streaming kernels: a thread keeps ONE column vector (its BN parameters live in registers) and strides over
 // rows; the global stride is rounded down to a multiple of the vectors per row so the column never changes.
 template <typename T, int V>
@@ -358,6 +373,13 @@ extern "C" int dm_bn_finalize(const float* psum, const float* psq, int nblk, int
 extern "C" int dm_col_reduce(const float* part, int nblk, int C, float* out, int accumulate, dm_stream_t s) {
     DM_CHECK_ARG(part && out && nblk > 0 && C > 0, "dm_col_reduce: bad arguments");
     hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)s, part, nblk, C, out, accumulate);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_col_reduce2(const float* part1, const float* part2, int nblk, int C, float* out1, float* out2, dm_stream_t s) {
+    DM_CHECK_ARG(part1 && part2 && out1 && out2 && nblk > 0 && C > 0, "dm_col_reduce2: bad arguments");
+    hipLaunchKernelGGL(col_reduce2_kernel, dim3(cdiv(2 * C, 4)), dim3(256), 0, (hipStream_t)s, part1, part2, nblk, C, out1, out2);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

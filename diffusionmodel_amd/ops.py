@@ -134,16 +134,23 @@ def packed_T(w, dtype, taps, np_):
     n, c = w.shape[0], w.shape[1]
     t = w.shape[2] * w.shape[3]
     taps = list(range(t)) if taps is None else list(taps)
+    return _packed_T_core(w, ("T", dtype, tuple(taps), np_), n, t, c, taps, np_, dtype)
 
-    key = ("T", dtype, tuple(taps), np_)
 
+def packed_T2d(w):
+    """[K][N] fp32 transpose of a dense-layer weight [N][K] (input gradient of the dense layers)."""
+    n, k = w.shape
+    return _packed_T_core(w, ("linT",), n, 1, k, [0], n, torch.float32)
+
+
+def _packed_T_core(w, key, n, t, c, taps, np_, dtype):
     def build():
         reg = _T_PACKS.get((id(w), key))
         if reg is not None and reg[0]() is w:
             out = reg[1]                          # re-pack in place: the batched refresh keeps pointing at this tensor
         else:
             out = _empty((c, len(taps), np_), dtype, w)
-            if len(taps) <= 16:
+            if len(taps) <= 16 and isinstance(w, torch.nn.Parameter):      # (views / temporaries stay on the lazy path)
                 _T_PACKS[(id(w), key)] = (weakref.ref(w), out, (n, t, c, tuple(taps), np_, dt(dtype)))
                 _T_TABLES.clear()
         arr = (C.c_int32 * len(taps))(*taps)
@@ -370,8 +377,7 @@ class ConvBnAct(torch.autograd.Function):
             call("dm_bn_act_bwd_reduce", ptr(z), ptr(g), dt(dtype), M, N, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), spec.act,
                  ptr(p1), ptr(p2))
             dbeta, dgamma = _empty((N,), torch.float32, g), _empty((N,), torch.float32, g)
-            call("dm_col_reduce", ptr(p1), nblk, N, ptr(dbeta), 0)
-            call("dm_col_reduce", ptr(p2), nblk, N, ptr(dgamma), 0)
+            call("dm_col_reduce2", ptr(p1), ptr(p2), nblk, N, ptr(dbeta), ptr(dgamma))
             dz = _empty(z.shape, dtype, g)
             if ctx.train:
                 s1, s2 = dbeta, dgamma
@@ -593,11 +599,7 @@ def _lin_bwd(x, w, g, dx, dw, db):
         call("dm_linear_bwd", ptr(x), ptr(w), ptr(g), ptr(dx), ptr(dw), ptr(db), M, K, N)
         return
     if dx is not None:
-        def build():
-            wt = _empty((K, N), torch.float32, w)
-            call("dm_pack_wT", ptr(w), ptr(wt), L.DM_F32, N, 1, K, 1, None, N)
-            return wt
-        wt = _cached(("linT",), w, build)
+        wt = packed_T2d(w)                       # refreshed with all other transposed packs after the optimiser step
         _conv_call(g, None, ptr(wt), N, dx, dtype=torch.float32, B=M, Hi=1, Wi=1, C1=N, C2=0, Hq=1, Wq=1, sy=1, sx=1,
                    T=1, KW=1, ty=1, tx=1, oy0=0, ox0=0, Ho=1, Wo=1, N=K)
     if dw is not None or db is not None:
@@ -693,8 +695,7 @@ class BnActMatrix(torch.autograd.Function):
         p1, p2 = _empty((nblk, Cc), torch.float32, z), _empty((nblk, Cc), torch.float32, z)
         call("dm_bn_act_bwd_reduce", ptr(z), ptr(g), L.DM_F32, M, Cc, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(p1), ptr(p2))
         dbeta, dgamma = _empty((Cc,), torch.float32, z), _empty((Cc,), torch.float32, z)
-        call("dm_col_reduce", ptr(p1), nblk, Cc, ptr(dbeta), 0)
-        call("dm_col_reduce", ptr(p2), nblk, Cc, ptr(dgamma), 0)
+        call("dm_col_reduce2", ptr(p1), ptr(p2), nblk, Cc, ptr(dbeta), ptr(dgamma))
         dz = _empty(z.shape, torch.float32, z)
         s1, s2 = (dbeta, dgamma) if train else (_gzeros((Cc,), z),) * 2
         call("dm_bn_act_bwd_apply", ptr(z), ptr(g), ptr(dz), L.DM_F32, M, Cc, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act,

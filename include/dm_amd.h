@@ -114,6 +114,8 @@ int dm_bn_act_bwd_reduce(const void* z, const void* dy, int dtype, int M, int C,
                          const float* gamma, const float* beta, int act, float* p1, float* p2, dm_stream_t s);
 /* reduce partials [nblk][C] -> out[C] (out = or += sum) */
 int dm_col_reduce(const float* part, int nblk, int C, float* out, int accumulate, dm_stream_t s);
+/* the same for two partial arrays of one shape in a single launch: out1 = sum(part1), out2 = sum(part2) */
+int dm_col_reduce2(const float* part1, const float* part2, int nblk, int C, float* out1, float* out2, dm_stream_t s);
 /* backward pass 2: dz = gamma*rstd*(g - s1/M - xhat*s2/M); s1 = dbeta, s2 = dgamma (already reduced) */
 int dm_bn_act_bwd_apply(const void* z, const void* dy, void* dz, int dtype, int M, int C, const float* mean,
                         const float* rstd, const float* gamma, const float* beta, int act,
