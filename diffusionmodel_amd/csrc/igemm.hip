@@ -526,10 +526,15 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
     const int C = p.C1 + p.C2;
     const int c_lo = split * p.kper;                       // this split's channel chunks [c_lo, nchunks)
     const int nchunks = min((C + 63) >> 6, c_lo + p.kper);    // a lone partial chunk (C < 64, single source) reads zeros past C
-    const int tiles_img = TW == 8 ? 1 : (p.Hi * TW) >> 8;
-    const int b = TW == 8 ? mb * 4 : mb / tiles_img, y0 = TW == 8 ? 0 : (mb - b * tiles_img) * TH;
+    // TW = 64 also serves wider images (Wi a multiple of 64): the tile is then 4 rows x 64 COLUMNS x0 .. x0+63 and its
+    // left / right halo columns are real pixels of the neighbouring tile
+    const int tcols = TW == 64 ? p.Wi >> 6 : 1;
+    const int tiles_img = TW == 8 ? 1 : ((p.Hi * TW) >> 8) * tcols;
+    const int b = TW == 8 ? mb * 4 : mb / tiles_img;
+    const int trem = mb - b * tiles_img;
+    const int y0 = TW == 8 ? 0 : (trem / tcols) * TH, x0 = (trem % tcols) * 64;
 
-    const int pix_img = p.B * p.Hi * TW;
+    const int pix_img = p.B * p.Hi * p.Wi;
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.N * p.ldw * 2, SRD_FLAGS);
 
     // ---- per-lane constants (nothing below changes inside the loop) ----
@@ -542,9 +547,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
         const int hp = q * 8 + lrow;
         const int hy = hp / HS, hx = hp - hy * HS;
         const int img = TW == 8 ? hx / 10 : 0;                     // TW = 8: image of the tile this halo column belongs to
-        const int y = y0 + hy - 1, x = TW == 8 ? hx - img * 10 - 1 : hx - 1;
-        const bool ok = (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)TW && img < 4;
-        const int pix = ((b + img) * p.Hi + y) * TW + x;
+        const int y = y0 + hy - 1, x = TW == 8 ? hx - img * 10 - 1 : x0 + hx - 1;
+        const bool ok = (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi && img < 4 && hx < TW + 2 + (TW == 8 ? 30 : 0);
+        const int pix = ((b + img) * p.Hi + y) * p.Wi + x;
         hv1[i] = ok && slotb < p.C1 * 2 ? (unsigned)(pix * p.C1 * 2 + slotb) : OOB;
         hv2[i] = ok ? (unsigned)(pix * p.C2 * 2 + slotb) : OOB;
     }
@@ -653,7 +658,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
         return;
     }
     const int tidh = (((wave & 1) + 2 * wn) << 6) + lane;
-    conv_epilogue<bf16, 128>(p, acc, smem + half * 4096, tidh, wm4 & 1, wn, fr, fg, mb * 2 + half, m0 + half * 128, n0);
+    // first output pixel of this wave's 64: linear in the tile for whole-row tiles, its own image row for column tiles
+    const int mw = (TW == 64 && tcols > 1) ? ((b * p.Hi + y0 + wm4) * p.Wi + x0) : m0 + wm4 * 64;
+    conv_epilogue<bf16, 128>(p, acc, smem + half * 4096, tidh, wm4 & 1, wn, fr, fg, mb * 2 + half, mw - (wm4 & 1) * 64, n0);
 }
 
 int g_variant = 5;    // 1 = register staging, 2..4 = LDS-DMA with that many ring stages (2 workgroups/CU at 2),
@@ -696,7 +703,7 @@ int launch_halo(const ConvP& p, hipStream_t st) {
     ConvP q = p;
     // few tiles, deep K (the 8x8 / 16x16 layers): split the channel chunks over workgroups until the chip is full
     const int nchunks = (p.C1 + p.C2 + 63) / 64;
-    if (tiles <= 128 && nchunks >= 4 && dm_g_ws != nullptr) {
+    if (tiles <= 128 && nchunks >= 4 && dm_g_ws != nullptr && p.Wi <= 64) {     // (the split epilogue assumes whole-row tiles)
         int splits = 256 / tiles;
         if (splits > nchunks / 2) splits = nchunks / 2;
         if (splits >= 2 && (int64_t)splits * tiles * 2 * (128 * 128 * 4) <= dm_g_ws_bytes) {
@@ -722,6 +729,8 @@ bool halo_eligible(const ConvP& p) {
     if (p.Hq != p.Hi || p.Wq != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi || p.osy != 1 || p.osx != 1 || p.ooy != 0 || p.oox != 0) return false;
     if (p.Wi == 8) {                                                   // four whole 8x8 images per tile
         if (p.Hi != 8 || p.B % 4 != 0) return false;
+    } else if (p.Wi > 64) {                                            // column tiles of 4 rows x 64 pixels
+        if (p.Wi % 64 != 0 || p.Hi % 4 != 0) return false;
     } else if ((p.Wi != 16 && p.Wi != 32 && p.Wi != 64) || (p.Hi * p.Wi) % 256 != 0) {
         return false;
     }
@@ -737,7 +746,7 @@ int launch_conv(const ConvP& p, bool small_offsets, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         if (g_variant == 5 && halo_eligible(p)) {
             const bool flip = p.ty < 0;
-            if (p.Wi == 64) return flip ? launch_halo<64, true>(p, st) : launch_halo<64, false>(p, st);
+            if (p.Wi >= 64) return flip ? launch_halo<64, true>(p, st) : launch_halo<64, false>(p, st);
             if (p.Wi == 32) return flip ? launch_halo<32, true>(p, st) : launch_halo<32, false>(p, st);
             if (p.Wi == 16) return flip ? launch_halo<16, true>(p, st) : launch_halo<16, false>(p, st);
             return flip ? launch_halo<8, true>(p, st) : launch_halo<8, false>(p, st);

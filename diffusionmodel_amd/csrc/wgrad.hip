@@ -404,7 +404,7 @@ constexpr int WGH_STAGE = WGH_DY + 36 * 1024;     // + halo image (36 pieces of 
 
 struct WgHP {
     const char* dy; const char* in1; const char* in2; float* dw; float* dbias; float* ws;
-    int B, Hi, C1, C2, N, ldy, ldw;
+    int B, Hi, Wi, C1, C2, N, ldy, ldw;
     int ntiles, nchunks, blocks, splits, tiles_per_split;
 };
 
@@ -433,7 +433,10 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
     const int Cs = first ? p.C1 : p.C2;
     const int cin0 = first ? c0 : c0 - p.C1;
     const int t_lo = split * p.tiles_per_split, t_hi = min(t_lo + p.tiles_per_split, p.ntiles);
-    const int tiles_img = TW == 8 ? 1 : (p.Hi * TW) >> 7;
+    // TW = 64 also serves wider images (Wi a multiple of 64): the tile is then 2 rows x 64 COLUMNS x0 .. x0+63
+    const int tcols = TW == 64 ? p.Wi >> 6 : 1;
+    const int RW = TW == 64 ? p.Wi : TW;                   // pixels per image row in memory
+    const int tiles_img = TW == 8 ? 1 : ((p.Hi * TW) >> 7) * tcols;
 
     const __amdgpu_buffer_rsrc_t rDY = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.ntiles * 128 * p.ldy * 2, WG_SRD);
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? p.in1 : p.in2), 0, p.ntiles * 128 * Cs * 2, WG_SRD);
@@ -455,44 +458,52 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
     const int strip = wave % (NC < 8 ? NC : 8), rgroup = wave / (NC < 8 ? NC : 8);
     const bool halo_wave = rgroup < RG;
     const int hy0 = rgroup * RPG;
-    int xv0, xv8 = 0;
-    bool xok0, xok8 = false;
+    int xv0, xv8 = 0, xedge0 = 0;
+    bool xok0, xok8 = false, xright8 = false;
     {
         const int hx = strip * 8 + (lane >> 3), s = lane & 7;
         const int lslot = ((((s >> 1) ^ ((hx >> 1) & 3)) << 1) | (s & 1));       // HS % 8 == 0: the swizzle follows hx only
         const int img = TW == 8 ? hx / 10 : 0;                                   // TW = 8: which of the tile's two images
         const int x = TW == 8 ? hx - img * 10 - 1 : hx - 1;
-        xv0 = ((hy0 - 1) * TW + img * 64 + x) * Cs * 2 + lslot * 16 + cin0 * 2;
+        xv0 = ((hy0 - 1) * RW + img * 64 + x) * Cs * 2 + lslot * 16 + cin0 * 2;
+        // column inside the tile; columns -1 and TW belong to the neighbouring column tile when there is one (xedge0: 1 = left, 2 = right)
         xok0 = (unsigned)x < (unsigned)TW && img < 2 && lslot * 8 < Cs;      // (a lone partial chunk, C < 64, reads zeros past C)
+        xedge0 = (TW == 64 && lslot * 8 < Cs) ? (x == -1 ? 1 : x == TW ? 2 : 0) : 0;
         if constexpr (TW == 64) {
             const int hx8 = 64 + (lane >> 3);
-            xv8 = ((wave - 1) * TW + hx8 - 1) * Cs * 2 + lslot * 16 + cin0 * 2;      // row `wave` of strip 8 (64 % 8 == 0: same lslot)
+            xv8 = ((wave - 1) * RW + hx8 - 1) * Cs * 2 + lslot * 16 + cin0 * 2;      // row `wave` of strip 8 (64 % 8 == 0: same lslot)
             xok8 = hx8 - 1 < TW && lslot * 8 < Cs;
+            xright8 = hx8 - 1 == TW && lslot * 8 < Cs;
         }
     }
     auto issue = [&](int stage, int tile) {
         char* sA = smem + stage * WGH_STAGE;
         char* sX = sA + WGH_DY;
-        const int soff = tile * 128 * p.ldy * 2;
+        const int bimg = tile / tiles_img, trem = tile - bimg * tiles_img;
+        const int y0 = TW == 8 ? 0 : (trem / tcols) * R, x0 = (trem % tcols) * 64;
+        const int pix0 = TW == 8 ? tile * 128 : (bimg * p.Hi + y0) * RW + x0;       // first pixel of the tile
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rDY, (lds_dst3)(sA + (j * 8 + wave) * 1024), 16, dyv, soff + j * 32 * p.ldy * 2, 0, 0);
-        const int y0 = (tile % tiles_img) * R;
+        for (int j = 0; j < 4; ++j) {                  // tile pixels 32 j .. 32 j + 31: (part of) one image row, or whole rows
+            const int prow = (TW == 64 && tcols > 1) ? pix0 + (j >> 1) * RW + (j & 1) * 32 : pix0 + j * 32;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rDY, (lds_dst3)(sA + (j * 8 + wave) * 1024), 16, dyv, prow * p.ldy * 2, 0, 0);
+        }
         const bool top = y0 == 0, bottom = y0 + R == p.Hi;                 // halo rows outside the image
-        const int tbase = tile * 128 * Cs * 2;
+        const bool has_left = x0 > 0, has_right = x0 + 64 < RW;            // neighbouring column tiles (TW = 64 only)
+        const int tbase = pix0 * Cs * 2;
         if (halo_wave) {
 #pragma unroll
             for (int i = 0; i < RPG; ++i) {
                 const int hy = hy0 + i;
                 const bool row_ok = !((hy == 0 && top) || (hy == HR - 1 && bottom));
-                const unsigned v = (xok0 && row_ok) ? (unsigned)(tbase + i * TW * Cs * 2 + xv0) : WG_OOB;
+                const bool col_ok = xok0 || (xedge0 == 1 && has_left) || (xedge0 == 2 && has_right);
+                const unsigned v = (col_ok && row_ok) ? (unsigned)(tbase + i * RW * Cs * 2 + xv0) : WG_OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_dst3)(sX + (hy * NC + strip) * 1024), 16, v, 0, 0, 0);
             }
         }
         if constexpr (TW == 64) {
             if (wave < 4) {
                 const bool row_ok = !((wave == 0 && top) || (wave == HR - 1 && bottom));
-                const unsigned v = (xok8 && row_ok) ? (unsigned)(tbase + xv8) : WG_OOB;
+                const unsigned v = ((xok8 || (xright8 && has_right)) && row_ok) ? (unsigned)(tbase + xv8) : WG_OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_dst3)(sX + (wave * NC + 8) * 1024), 16, v, 0, 0, 0);
             }
         }
@@ -712,6 +723,8 @@ bool wgrad_halo_plan(const DmWgrad* d, int64_t M, WgHP& hp) {
     if (d->Hq != d->Hi || d->Wq != d->Wi || d->Ho != d->Hq || d->Wo != d->Wq || d->osy != 1 || d->osx != 1 || d->ooy != 0 || d->oox != 0) return false;
     if (d->Wi == 8) {                                                  // two whole 8x8 images per tile
         if (d->Hi != 8 || d->B % 2 != 0) return false;
+    } else if (d->Wi > 64) {                                           // column tiles of 2 rows x 64 pixels
+        if (d->Wi % 64 != 0 || d->Hi % 2 != 0) return false;
     } else if ((d->Wi != 16 && d->Wi != 32 && d->Wi != 64) || (d->Hi * d->Wi) % 128 != 0) {
         return false;
     }
@@ -722,7 +735,7 @@ bool wgrad_halo_plan(const DmWgrad* d, int64_t M, WgHP& hp) {
     if (((uintptr_t)d->dy & 15) || ((uintptr_t)d->in1 & 15) || ((uintptr_t)d->in2 & 15)) return false;
     const int C = d->C1 + d->C2;
     hp.dy = (const char*)d->dy; hp.in1 = (const char*)d->in1; hp.in2 = (const char*)d->in2; hp.dw = d->dw; hp.dbias = d->dbias; hp.ws = dm_g_ws;
-    hp.B = d->B; hp.Hi = d->Hi; hp.C1 = d->C1; hp.C2 = d->C2; hp.N = d->N; hp.ldy = d->ldy; hp.ldw = d->ldw;
+    hp.B = d->B; hp.Hi = d->Hi; hp.Wi = d->Wi; hp.C1 = d->C1; hp.C2 = d->C2; hp.N = d->N; hp.ldy = d->ldy; hp.ldw = d->ldw;
     hp.ntiles = (int)(M / 128);
     hp.nchunks = (C + 63) / 64;
     hp.blocks = cdiv(d->N, 128) * hp.nchunks;
@@ -760,7 +773,7 @@ extern "C" int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream) {
     DM_CHECK_ARG((int64_t)d->T * cdiv(d->C1 + d->C2, 128) < 65536, "dm_conv_wgrad: grid.y too large");
     WgHP hp;
     if (wgrad_halo_plan(d, M, hp)) {
-        if (d->Wi == 64) return launch_wgrad_halo<64>(hp, (hipStream_t)stream);
+        if (d->Wi >= 64) return launch_wgrad_halo<64>(hp, (hipStream_t)stream);
         if (d->Wi == 32) return launch_wgrad_halo<32>(hp, (hipStream_t)stream);
         if (d->Wi == 16) return launch_wgrad_halo<16>(hp, (hipStream_t)stream);
         return launch_wgrad_halo<8>(hp, (hipStream_t)stream);

@@ -125,6 +125,8 @@ HALO_CASES = [
     (8, 128, 64, 192, 8),    # 8x8, two tiles, concatenated sources, two n-tiles
     (2, 8, 0, 128, 32),      # one partial chunk (the 8-channel stem / head-gradient layers)
     (4, 8, 0, 24, 16),       # partial chunk and partial n tile
+    (1, 64, 0, 64, 128),     # 128-pixel rows: column tiles of 64, halo columns come from the neighbouring tile
+    (2, 64, 64, 136, 128),   # column tiles, concatenated sources, ragged N
 ]
 
 
