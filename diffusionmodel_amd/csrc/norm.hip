@@ -325,6 +325,103 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* x, const T* dy, T*
     }
 }
 
+// 16-byte-vector forms of the two kernels above (cg % VE == 0, 256 % (cg / VE) == 0, aligned): a thread keeps ONE channel
+// vector of the group (its gamma / beta live in registers) and strides over pixels; the second pass re-reads from L2 / MALL.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void gn_fwd_vec_kernel(const T* x, T* y, int HW, int C, int G, float eps, const float* gamma,
+                                                         const float* beta, int act, float* mean_o, float* rstd_o) {
+    __shared__ float red[16];
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int cg = C / G, cv = cg / V;                 // vectors per pixel of this group
+    const int v0 = threadIdx.x % cv, p0 = threadIdx.x / cv, pstep = 256 / cv;
+    const size_t base = (size_t)b * HW * C + g * cg + v0 * V;
+    float gm[V], bt[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { gm[k] = gamma[g * cg + v0 * V + k]; bt[k] = beta[g * cg + v0 * V + k]; }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+    for (int pix = p0; pix < HW; pix += pstep) {
+        float v[V];
+        load_vec<T>(x + base + (size_t)pix * C, v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) { s1 += v[k]; s2 += v[k] * v[k]; }
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    const float n = (float)HW * cg;
+    const float mu = s1 / n;
+    float var = s2 / n - mu * mu;
+    var = var < 0.f ? 0.f : var;
+    const float rs = rsqrtf(var + eps);
+    if (threadIdx.x == 0) { mean_o[blockIdx.x] = mu; rstd_o[blockIdx.x] = rs; }
+#pragma unroll 4
+    for (int pix = p0; pix < HW; pix += pstep) {
+        float v[V];
+        load_vec<T>(x + base + (size_t)pix * C, v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) v[k] = act_apply_t<T>((v[k] - mu) * rs * gm[k] + bt[k], act);
+        store_vec<T>(y + base + (size_t)pix * C, v);
+    }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void gn_bwd_vec_kernel(const T* x, const T* dy, T* dx, int HW, int C, int G, const float* gamma,
+                                                         const float* beta, int act, const float* mean_i, const float* rstd_i,
+                                                         float* dgamma, float* dbeta) {
+    __shared__ float red[16];
+    extern __shared__ float chacc[];  // [2][cg]
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int cg = C / G, cv = cg / V;
+    const int v0 = threadIdx.x % cv, p0 = threadIdx.x / cv, pstep = 256 / cv;
+    const size_t base = (size_t)b * HW * C + g * cg + v0 * V;
+    const float mu = mean_i[blockIdx.x], rs = rstd_i[blockIdx.x];
+    float gm[V], bt[V], a1[V], a2[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { gm[k] = gamma[g * cg + v0 * V + k]; bt[k] = beta[g * cg + v0 * V + k]; a1[k] = 0.f; a2[k] = 0.f; }
+    for (int i = threadIdx.x; i < 2 * cg; i += 256) chacc[i] = 0.f;
+    __syncthreads();
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 2
+    for (int pix = p0; pix < HW; pix += pstep) {
+        float xv[V], gv[V];
+        load_vec<T>(x + base + (size_t)pix * C, xv);
+        load_vec<T>(dy + base + (size_t)pix * C, gv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float xh = (xv[k] - mu) * rs;
+            const float gg = gv[k] * act_grad_t<T>(xh * gm[k] + bt[k], act);
+            s1 += gg * gm[k];
+            s2 += gg * gm[k] * xh;
+            a1[k] += gg;
+            a2[k] += gg * xh;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) { atomicAdd(&chacc[v0 * V + k], a1[k]); atomicAdd(&chacc[cg + v0 * V + k], a2[k]); }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cg; i += 256) {
+        atomicAdd(dbeta + g * cg + i, chacc[i]);
+        atomicAdd(dgamma + g * cg + i, chacc[cg + i]);
+    }
+    const float n = (float)HW * cg;
+    const float m1 = s1 / n, m2 = s2 / n;
+#pragma unroll 2
+    for (int pix = p0; pix < HW; pix += pstep) {
+        float xv[V], gv[V];
+        load_vec<T>(x + base + (size_t)pix * C, xv);
+        load_vec<T>(dy + base + (size_t)pix * C, gv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float xh = (xv[k] - mu) * rs;
+            const float gg = gv[k] * act_grad_t<T>(xh * gm[k] + bt[k], act);
+            xv[k] = rs * (gg * gm[k] - m1 - xh * m2);
+        }
+        store_vec<T>(dx + base + (size_t)pix * C, xv);
+    }
+}
+
 // grid of the per-thread-column streaming kernels: >= 8 vectors per thread (the 4 x V channel parameters a
 // thread keeps in registers are then amortised), at most 8 workgroups per CU, at least one pass over a row
 int stream_grid(int64_t nvec, int cv) {
@@ -443,7 +540,14 @@ extern "C" int dm_bn_fold(const float* gamma, const float* beta, const float* rm
 extern "C" int dm_gn_act_fwd(const void* x, void* y, int dtype, int B, int HW, int C, int G, float eps, const float* gamma,
                              const float* beta, int act, float* mean, float* rstd, dm_stream_t s) {
     DM_CHECK_ARG(x && y && gamma && beta && mean && rstd && B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "dm_gn_act_fwd: bad arguments");
-    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_fwd_kernel<T>), dim3(B * G), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, HW, C, G, eps, gamma, beta, act, mean, rstd));
+    DM_DISPATCH_DTYPE(dtype, {
+        constexpr int V = Elem<T>::VE;
+        const int cg = C / G;
+        if (cg % V == 0 && 256 % (cg / V) == 0 && C % V == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
+            hipLaunchKernelGGL((gn_fwd_vec_kernel<T, V>), dim3(B * G), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, HW, C, G, eps, gamma, beta, act, mean, rstd);
+        else
+            hipLaunchKernelGGL((gn_fwd_kernel<T>), dim3(B * G), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, HW, C, G, eps, gamma, beta, act, mean, rstd);
+    });
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
@@ -453,7 +557,14 @@ extern "C" int dm_gn_act_bwd(const void* x, const void* dy, void* dx, int dtype,
                              dm_stream_t s) {
     DM_CHECK_ARG(x && dy && dx && gamma && beta && mean && rstd && dgamma && dbeta && B > 0 && HW > 0 && C % G == 0, "dm_gn_act_bwd: bad arguments");
     const size_t shm = 2 * (C / G) * sizeof(float);
-    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_bwd_kernel<T>), dim3(B * G), dim3(256), shm, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, HW, C, G, gamma, beta, act, mean, rstd, dgamma, dbeta));
+    DM_DISPATCH_DTYPE(dtype, {
+        constexpr int V = Elem<T>::VE;
+        const int cg = C / G;
+        if (cg % V == 0 && 256 % (cg / V) == 0 && C % V == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0)
+            hipLaunchKernelGGL((gn_bwd_vec_kernel<T, V>), dim3(B * G), dim3(256), shm, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, HW, C, G, gamma, beta, act, mean, rstd, dgamma, dbeta);
+        else
+            hipLaunchKernelGGL((gn_bwd_kernel<T>), dim3(B * G), dim3(256), shm, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, HW, C, G, gamma, beta, act, mean, rstd, dgamma, dbeta);
+    });
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

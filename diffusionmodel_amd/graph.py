@@ -83,5 +83,7 @@ class GraphedTrainStep:
         self.opt._step += 1
         self.ddpm._rng_calls += 1
         self.replays += 1
-        ops.bump_weight_epoch()                            # eager code that follows must not trust host-side pack stamps
+        # (packed weights: every pack is either refreshed by the captured optimiser step (bf16 shadow, registered transposes) or
+        #  was stale at capture time and is therefore rebuilt inside the graph, so eager code that follows finds fresh contents
+        #  behind the stamps the capture left)
         return self.loss

@@ -24,6 +24,7 @@ BN_EPS = 1e-5
 _EPOCH = [0]          # bumped by the fused optimiser: invalidates packed-weight caches
 _CACHE = {}
 ON_WGRAD = None       # parallel.GradReducer: called with the parameter whose main_grad a weight-gradient launch just completed
+PROFILE_KINDS = ("conv_igemm", "conv_wgrad", "igemm_f32", "wgrad_f32")   # bench.py narrows this to the kinds it reports
 PROFILE = None        # bench.py sets this to a list to collect (kind, flops, start_event, end_event, shape)
 
 
@@ -226,14 +227,15 @@ def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, s
     d.T, d.KW, d.ty, d.tx, d.oy0, d.ox0 = T, KW, ty, tx, oy0, ox0
     d.Ho, d.Wo, d.osy, d.osx, d.ooy, d.oox = Ho, Wo, osy, osx, ooy, oox
     d.N, d.ldw, d.ldc, d.coff = N, ldw, (N if ldc is None else ldc), coff
-    if PROFILE is None:
+    kind = "conv_igemm" if dtype == torch.bfloat16 else "igemm_f32"
+    if PROFILE is None or kind not in PROFILE_KINDS:
         call("dm_conv", C.byref(d))
     else:   # bench.py: HIP events on the launch stream around this launch + its algorithmic FLOPs
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         call("dm_conv", C.byref(d))
         e1.record()
-        PROFILE.append(("conv_igemm" if dtype == torch.bfloat16 else "igemm_f32", 2.0 * B * Hq * Wq * N * T * (C1 + C2), e0, e1,
+        PROFILE.append((kind, 2.0 * B * Hq * Wq * N * T * (C1 + C2), e0, e1,
                         f"B{B} {Hi}x{Wi} C{C1}+{C2} N{N} T{T} s{sy} t{ty} o{oy0} out{Ho}x{Wo}/{osy}"))
 
 
@@ -248,14 +250,15 @@ def _wgrad_call(dy, in1, in2, dw, dbias, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy
     d.T, d.KW, d.ty, d.tx, d.oy0, d.ox0 = T, KW, ty, tx, oy0, ox0
     d.Ho, d.Wo, d.osy, d.osx, d.ooy, d.oox = Ho, Wo, osy, osx, ooy, oox
     d.N, d.ldy, d.ldw, d.splitk = N, ldy, ldw, splitk
-    if PROFILE is None:
+    kind = "conv_wgrad" if dtype == torch.bfloat16 else "wgrad_f32"
+    if PROFILE is None or kind not in PROFILE_KINDS:
         call("dm_conv_wgrad", C.byref(d))
     else:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         call("dm_conv_wgrad", C.byref(d))
         e1.record()
-        PROFILE.append(("conv_wgrad" if dtype == torch.bfloat16 else "wgrad_f32", 2.0 * B * Hq * Wq * N * T * (C1 + C2), e0, e1,
+        PROFILE.append((kind, 2.0 * B * Hq * Wq * N * T * (C1 + C2), e0, e1,
                         f"B{B} {Hi}x{Wi} C{C1}+{C2} N{N} T{T} s{sy} q{Hq}x{Wq}"))
 
 
