@@ -146,7 +146,15 @@ def ensure_workspace():
     return _workspace
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_device = getattr(torch._C, "_cuda_getDevice", torch.cuda.current_device)
+
+
 def _stream():
+    """Raw handle of torch's current HIP stream on the current device.  torch.cuda.current_stream() costs ~9 us of Python per
+    call (1200 launches per train step); the private raw-stream getter is a plain C call."""
+    if _raw_stream is not None:
+        return _raw_stream(_get_device())
     return torch.cuda.current_stream().cuda_stream
 
 
