@@ -509,3 +509,42 @@ def test_bn_act_matrix_strips(M, Cc, train):
     assert rel_err(bn_d.bias.grad.cpu(), bn_r.bias.grad) < 5e-5
     if train:
         assert rel_err(bn_d.running_var.cpu(), bn_r.running_var) < 1e-5
+
+
+def test_batched_pack_device_rng_offset_and_paired_reduce():
+    """The launch-saving entry points against the single-purpose ones they replace:
+    dm_pack_multi == dm_pack_wT per tensor, dm_randn_dev(offset on device) == dm_randn(offset), dm_col_reduce2 == 2 x dm_col_reduce."""
+    import ctypes as C
+    from diffusionmodel_amd._lib import call, ptr, DM_BF16, DM_F32
+    # ---- dm_pack_multi: two tensors, different tap subsets / dtypes
+    specs = [(24, 9, 40, [0, 2, 4, 8], 24, torch.bfloat16), (7, 4, 16, [1, 3], 8, torch.float32)]   # N, T, C, taps, Np, dtype
+    srcs, refs, outs, ents, taps_rows, blocks = [], [], [], [], [], []
+    for e, (N, T, Cc, taps, Np, dtp) in enumerate(specs):
+        src = torch.randn(N, T, Cc, device=DEV)
+        ref = torch.empty(Cc, len(taps), Np, device=DEV, dtype=dtp)
+        out = torch.full_like(ref, 7.0)
+        code = DM_BF16 if dtp == torch.bfloat16 else DM_F32
+        call("dm_pack_wT", ptr(src), ptr(ref), code, N, T, Cc, len(taps), (C.c_int32 * len(taps))(*taps), Np)
+        ents.append((src.data_ptr(), out.data_ptr(), N, T, Cc, len(taps), Np, code))
+        taps_rows.append(taps + [0] * (16 - len(taps)))
+        blocks += [(e, nt, ct, tt) for tt in range(len(taps)) for ct in range((Cc + 31) // 32) for nt in range((Np + 31) // 32)]
+        srcs.append(src); refs.append(ref); outs.append(out)
+    t_e = torch.tensor(ents, dtype=torch.int64).to(DEV)
+    t_t = torch.tensor(taps_rows, dtype=torch.int32).to(DEV)
+    t_b = torch.tensor(blocks, dtype=torch.int32).to(DEV)
+    call("dm_pack_multi", ptr(t_e), ptr(t_t), ptr(t_b), len(blocks))
+    for ref, out in zip(refs, outs):
+        assert torch.equal(ref, out)
+    # ---- dm_randn_dev
+    a, b = torch.empty(1000, device=DEV), torch.empty(1000, device=DEV)
+    off = torch.tensor([12345], dtype=torch.int64, device=DEV)
+    call("dm_randn", ptr(a), 1000, 77, 12345)
+    call("dm_randn_dev", ptr(b), 1000, 77, ptr(off))
+    assert torch.equal(a, b)
+    # ---- dm_col_reduce2
+    p1, p2 = torch.randn(37, 20, device=DEV), torch.randn(37, 20, device=DEV)
+    o1, o2, r1, r2 = (torch.empty(20, device=DEV) for _ in range(4))
+    call("dm_col_reduce", ptr(p1), 37, 20, ptr(r1), 0)
+    call("dm_col_reduce", ptr(p2), 37, 20, ptr(r2), 0)
+    call("dm_col_reduce2", ptr(p1), ptr(p2), 37, 20, ptr(o1), ptr(o2))
+    assert torch.equal(o1, r1) and torch.equal(o2, r2)
