@@ -107,6 +107,9 @@ class OverlappedGradReducer:
         self.flat = opt.flat_g
         self.active = dist.is_initialized()
         self._stream = torch.cuda.Stream() if self.flat.is_cuda else None
+        # RCCL orders a collective after the work already queued on the stream it is issued from; gloo stages device tensors
+        # through the host on its own schedule, so with gloo (rehearsals on one GPU) the device is drained before every launch
+        self._drain = self.active and self.flat.is_cuda and dist.get_backend(group) != "nccl"
         slots = opt._slots                                        # (param, offset, numel) in flat-buffer order
         main = [(i, p, off, n) for i, (p, off, n) in enumerate(slots) if hasattr(p, "main_grad")]
         total_main = sum(n for _, _, _, n in main)
@@ -122,17 +125,20 @@ class OverlappedGradReducer:
                 hi = off + (n + 3) // 4 * 4 if not last else self.flat.numel()
                 self.buckets.append({"lo": lo, "hi": hi, "slots": range(lo_slot, i + 1)})
                 lo_slot, acc = i + 1, 0
-        self._bucket_of, self._need = {}, []
+        # Which parameters report through ON_WGRAD (their weight-gradient kernel wrote the flat buffer) and which arrive as
+        # autograd `.grad` tensors is a property of the layers' code paths, not of the parameter's shape (the 1x1 convolutions
+        # of CoordAttn own a main_grad view but run as dense layers and deliver a `.grad`).  So the first step only observes:
+        # every bucket is reduced after backward, the notifying parameters and the `.grad` parameters are recorded, and from
+        # the second step on buckets launch as soon as their notifying parameters are in.
+        self._slot_of = {id(p): i for i, (p, _, _) in enumerate(slots)}
+        self._bucket_of_slot = [0] * len(slots)
         for b, bk in enumerate(self.buckets):
-            ids = [id(slots[i][0]) for i in bk["slots"] if hasattr(slots[i][0], "main_grad")]
-            for k in ids:
-                self._bucket_of[k] = b
-            self._need.append(len(ids))
-        # everything that is not a main-grad weight: packed into one contiguous buffer for a single late all-reduce
-        self._small = [(off, n) for (p, off, n) in slots if not hasattr(p, "main_grad")]
-        self._small_total = sum((n + 3) // 4 * 4 for _, n in self._small)
-        self._packed = torch.zeros(max(self._small_total, 4), dtype=torch.float32, device=self.flat.device)
-        self._tables = None
+            for i in bk["slots"]:
+                self._bucket_of_slot[i] = b
+        self._learned, self._seen = False, set()
+        self._bucket_of, self._need = {}, [0] * len(self.buckets)
+        self._small, self._small_key, self._small_total = [], None, 0
+        self._packed, self._tables = None, None
         self._pending, self._launched, self._works = [], [], []
 
     # ---- per step ----------------------------------------------------------------------------
@@ -140,9 +146,13 @@ class OverlappedGradReducer:
         self._pending = list(self._need)
         self._launched = [False] * len(self.buckets)
         self._works = []
+        self._seen = set()
         self._ops.ON_WGRAD = self._notify if self.active else None
 
     def _notify(self, p):
+        if not self._learned:                         # observation step: just record who reports
+            self._seen.add(id(p))
+            return
         b = self._bucket_of.get(id(p))
         if b is None or self._launched[b]:
             return
@@ -154,6 +164,8 @@ class OverlappedGradReducer:
         self._launched[b] = True
         bk = self.buckets[b]
         view = self.flat[bk["lo"]:bk["hi"]]
+        if self._drain:
+            torch.cuda.synchronize()
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())          # the weight gradients launched so far
             with torch.cuda.stream(self._stream):
@@ -193,18 +205,34 @@ class OverlappedGradReducer:
         self._ops.ON_WGRAD = None
         if not self.active:
             return
+        if not self._learned:
+            self._bucket_of = {k: self._bucket_of_slot[self._slot_of[k]] for k in self._seen if k in self._slot_of}
+            self._need = [0] * len(self.buckets)
+            for b in self._bucket_of.values():
+                self._need[b] += 1
+            self._need = [n if n > 0 else 1 << 30 for n in self._need]     # a bucket nobody reports into waits for finish()
+            self._learned = True
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
-        # the early reductions summed zeros in the small slots; nothing else may touch those slots until they are done
+        # the early reductions summed zeros in the `.grad` slots; nothing else may touch those slots until they are done
         for w in self._works:
             w.wait()
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
         self._works = []
-        self.opt.gather_grads()                       # local small gradients into their (still local) slots
+        # the parameters whose gradient is an autograd `.grad` right now are exactly the slots the buckets have not covered
+        small = [(off, n) for (p, off, n) in self.opt._slots if p.grad is not None]
+        key = tuple(small)
+        if key != self._small_key:
+            self._small, self._small_key, self._tables = small, key, None
+            self._small_total = sum((n + 3) // 4 * 4 for _, n in small)
+            self._packed = torch.zeros(max(self._small_total, 4), dtype=torch.float32, device=self.flat.device)
+        self.opt.gather_grads()                       # local `.grad` gradients into their (still local) slots
         if self._small_total:
             self._copy_small(True)
+            if self._drain:
+                torch.cuda.synchronize()
             dist.all_reduce(self._packed, op=dist.ReduceOp.SUM, group=self.group)
             self._copy_small(False)
 

@@ -438,3 +438,17 @@ def test_graphed_train_step_matches_eager_and_leaves_state_alone():
     loss.backward()
     ob.step()
     assert torch.isfinite(loss).item()
+
+
+def test_overlapped_gradient_reducer_two_ranks_on_one_gpu():
+    """scripts/dp_rehearsal.py: two gloo ranks sharing cuda:0 run the real backward pass through OverlappedGradReducer
+    (observation step + two overlapped steps) and compare the reduced flat gradient with a blocking host-side sum."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29700 + os.getpid() % 200
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "scripts", "dp_rehearsal.py")],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "step 2" in r.stdout and "4/4" in r.stdout, r.stdout[-1500:]

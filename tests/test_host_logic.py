@@ -165,6 +165,7 @@ def test_gloo_data_parallel_matches_accumulation(tmp_path):
 class _FakeParam:
     def __init__(self, n, main):
         self.n = n
+        self.grad = None
         if main:
             self.main_grad = None            # attribute presence = "the wgrad kernel writes the flat buffer directly"
 
@@ -178,12 +179,12 @@ class _FakeOpt:
             self._slots.append((_FakeParam(n, main), off, n))
             off += (n + 3) // 4 * 4
         self.flat_g = torch.zeros(off)
-        self.small_local = {}
 
     def gather_grads(self):
         for (p, off, n) in self._slots:
-            if id(p) in self.small_local:
-                self.flat_g[off:off + n] += self.small_local.pop(id(p))
+            if p.grad is not None:
+                self.flat_g[off:off + n] += p.grad
+                p.grad = None
 
 
 def _overlap_worker(rank, world, port, out_dir):
@@ -191,25 +192,32 @@ def _overlap_worker(rank, world, port, out_dir):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from diffusionmodel_amd import ops
     parallel.init_from_env("gloo")
-    layout = [(37, True), (5, False), (1000, True), (8, False), (8, False), (513, True), (3, False), (2048, True), (64, False), (700, True)]
-    opt = _FakeOpt(layout)
+    # (size, has a main_grad view, its layer really writes the flat buffer and notifies): the third kind — a main_grad view
+    # that is never used because the layer runs as a dense layer and hands autograd a .grad — is what CoordAttn's 1x1 convs are
+    layout = [(37, True, True), (5, False, False), (1000, True, True), (8, False, False), (260, True, False), (513, True, True),
+              (3, False, False), (2048, True, True), (64, False, False), (700, True, True), (16, True, False)]
+    opt = _FakeOpt([(n, m) for n, m, _ in layout])
+    notifies = [nt for _, _, nt in layout]
     red = parallel.OverlappedGradReducer(opt, n_buckets=3)
     g = torch.Generator().manual_seed(100 + rank)
     expect_local = torch.zeros_like(opt.flat_g)
-    for step in range(2):                                        # two steps: per-step state must reset
+    early = []
+    for step in range(3):                                        # step 0 observes, steps 1-2 overlap; per-step state must reset
         opt.flat_g.zero_()
         expect_local.zero_()
         red.begin()
-        for (p, off, n) in reversed(opt._slots):                 # "backward": last layer first
+        for (p, off, n), nt in reversed(list(zip(opt._slots, notifies))):      # "backward": last layer first
             v = torch.randn(n, generator=g)
             expect_local[off:off + n] = v
-            if hasattr(p, "main_grad"):
+            if nt:
                 opt.flat_g[off:off + n] = v                      # what the weight-gradient kernel does
                 ops.ON_WGRAD(p)
             else:
-                opt.small_local[id(p)] = v                       # autograd .grad, folded in by gather_grads()
+                p.grad = v                                       # autograd .grad, folded in by gather_grads()
+        early.append(sum(red._launched))
         red.finish()
         assert ops.ON_WGRAD is None
+    assert early[0] == 0 and early[1] > 0 and early[2] > 0, early
     torch.save((opt.flat_g.clone(), expect_local), os.path.join(out_dir, f"ov_{rank}.pt"))
     torch.distributed.destroy_process_group()
 
