@@ -81,13 +81,38 @@ def build_model(n_classes, device):
     return DDPM(nn_model=net, betas=Cfg.BETAS, n_T=Cfg.N_T, device=device, drop_prob=Cfg.DROP_PROB)
 
 
-def train_model(n_classes=4, n_train=64, n_val=16, max_epochs=None, device="cuda:0", quiet=False):
+def split_indices(labels, val_split, seed=42):
+    """Per-class (stratified) train / validation split of sample indices, like the reference's split (new_scripy.py:622-657)."""
+    g = torch.Generator().manual_seed(seed)
+    tr, va = [], []
+    for cls in sorted(set(labels)):
+        idx = [i for i, l in enumerate(labels) if l == cls]
+        perm = [idx[j] for j in torch.randperm(len(idx), generator=g).tolist()]
+        n_val = max(1, int(len(perm) * val_split)) if len(perm) > 1 else 0
+        va += perm[:n_val]
+        tr += perm[n_val:]
+    return tr, va
+
+
+def train_model(n_classes=4, n_train=64, n_val=16, max_epochs=None, device="cuda:0", quiet=False, data_root=None):
     os.makedirs(Cfg.SAVE_DIR, exist_ok=True)
     os.makedirs(Cfg.SAMPLE_DIR, exist_ok=True)
     S = Cfg.IMG_SIZE
-    train_ds = SyntheticCrackDataset(n_train, S, n_classes, seed=0)
-    val_ds = SyntheticCrackDataset(n_val, S, n_classes, seed=1)
-    train_dl = torch.utils.data.DataLoader(train_ds, batch_size=Cfg.BATCH_SIZE, shuffle=True, drop_last=True)
+    to_mask = lambda am: am.to(device)
+    if data_root:       # the reference's layout (images/<class>/..., annotations/*.xml); masks are rasterised on the device
+        from diffusionmodel_amd.data import CrackDataset, attn_masks
+        full = CrackDataset(data_root, S, return_boxes=True)
+        n_classes = len(full.classes)
+        tr_idx, va_idx = split_indices([s[2] for s in full.samples], Cfg.VAL_SPLIT)
+        train_ds, val_ds = torch.utils.data.Subset(full, tr_idx), torch.utils.data.Subset(full, va_idx)
+        to_mask = lambda boxes: attn_masks(boxes.tolist(), S, device)
+        if not quiet:
+            print(f"{data_root}: {len(full)} images, classes {full.classes}, {len(tr_idx)} train / {len(va_idx)} val")
+    else:
+        train_ds = SyntheticCrackDataset(n_train, S, n_classes, seed=0)
+        val_ds = SyntheticCrackDataset(n_val, S, n_classes, seed=1)
+    train_dl = torch.utils.data.DataLoader(train_ds, batch_size=Cfg.BATCH_SIZE, shuffle=True, drop_last=True,
+                                           num_workers=Cfg.NUM_WORKERS if data_root else 0)
     val_dl = torch.utils.data.DataLoader(val_ds, batch_size=Cfg.BATCH_SIZE)
     ddpm = build_model(n_classes, device)
     optim = FusedAdamW(ddpm.parameters(), lr=Cfg.LR, weight_decay=Cfg.WD, max_grad_norm=1.0)
@@ -101,7 +126,7 @@ def train_model(n_classes=4, n_train=64, n_val=16, max_epochs=None, device="cuda
         optim.zero_grad()
         losses = []
         for it, (x, c, am) in enumerate(train_dl):
-            loss = ddpm(x.to(device), c.to(device), am.to(device)) / Cfg.ACCUM_STEPS      # :785-786
+            loss = ddpm(x.to(device), c.to(device), to_mask(am)) / Cfg.ACCUM_STEPS          # :785-786
             loss.backward()
             losses.append(loss.detach())
             if (it + 1) % Cfg.ACCUM_STEPS == 0:                                            # :795-803
@@ -109,7 +134,7 @@ def train_model(n_classes=4, n_train=64, n_val=16, max_epochs=None, device="cuda
                 optim.zero_grad()
         ddpm.eval()                                                                        # :818-835
         with torch.no_grad():
-            vl = [ddpm(x.to(device), c.to(device), am.to(device)) for x, c, am in val_dl]
+            vl = [ddpm(x.to(device), c.to(device), to_mask(am)) for x, c, am in val_dl]
         tr = float(torch.stack(losses).mean()) * Cfg.ACCUM_STEPS
         va = float(torch.stack(vl).mean())
         history.append({"epoch": ep, "train_loss": tr, "val_loss": va, "lr": optim.param_groups[0]["lr"], "time": time.time() - t0})
@@ -168,13 +193,21 @@ def main(argv=None):
     ap.add_argument("--batch_size", type=int, default=None)
     ap.add_argument("--dtype", choices=["float32", "bfloat16"], default=None)
     ap.add_argument("--bottleneck_k", type=int, default=None)
+    ap.add_argument("--data_root", default=None, help="dataset in the reference's layout (images/<class>/*.jpg + annotations/*.xml); "
+                                                      "default: synthetic tensors")
+    ap.add_argument("--convert_supervisely", nargs=2, metavar=("SPLIT_DIR", "DST_ROOT"), default=None,
+                    help="lay a DatasetNinja / Supervisely split (img/ + ann/*.json, e.g. the bundled road-damage set) out as --data_root and exit")
     a = ap.parse_args(argv)
+    if a.convert_supervisely:
+        from diffusionmodel_amd.data import convert_supervisely
+        print(f"wrote {convert_supervisely(*a.convert_supervisely)} images under {a.convert_supervisely[1]}")
+        return
     for name, val in (("IMG_SIZE", a.img_size), ("N_FEAT", a.n_feat), ("N_T", a.n_T), ("BATCH_SIZE", a.batch_size),
                       ("DTYPE", a.dtype), ("BOTTLENECK_K", a.bottleneck_k)):
         if val is not None:
             setattr(Cfg, name, val)
     if a.mode == "train":
-        train_model(max_epochs=a.epochs)
+        train_model(max_epochs=a.epochs, data_root=a.data_root)
     else:
         if not a.ckpt:
             ap.error("--mode generate needs --ckpt/--checkpoint")
