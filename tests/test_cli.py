@@ -13,7 +13,7 @@ def test_cli_accepts_both_flag_spellings(monkeypatch):
     import new_scripy as ns
     calls = {}
     monkeypatch.setattr(ns, "gen_samples", lambda ckpt, n, scales: calls.update(ckpt=ckpt, n=n, scales=scales))
-    monkeypatch.setattr(ns, "train_model", lambda max_epochs=None: calls.update(train=max_epochs))
+    monkeypatch.setattr(ns, "train_model", lambda max_epochs=None, data_root=None: calls.update(train=max_epochs))
     ns.main(["--mode", "generate", "--ckpt", "a.pt", "--guide_scales", "2", "4", "--samples", "5", "--no_eval"])
     assert calls == {"ckpt": "a.pt", "n": 5, "scales": [2.0, 4.0]}
     calls.clear()
