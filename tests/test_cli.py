@@ -60,3 +60,36 @@ def test_train_then_generate_synthetic(tmp_path, monkeypatch):
     finally:
         for k, v in saved.items():
             setattr(Cfg, k, v)
+
+
+@pytest.mark.gpu
+def test_train_on_dataset_directory(tmp_path):
+    """--data_root path: images + VOC-XML on disk -> CrackDataset -> boxes -> masks rasterised on the device -> train step."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from PIL import Image
+    import new_scripy as ns
+    from diffusionmodel_amd import Cfg
+    root = str(tmp_path / "ds")
+    g = torch.Generator().manual_seed(0)
+    for ci, cls in enumerate(("crack_a", "crack_b")):
+        os.makedirs(os.path.join(root, "images", cls), exist_ok=True)
+        os.makedirs(os.path.join(root, "annotations"), exist_ok=True)
+        for j in range(10):
+            name = f"{cls}_{j}"
+            arr = (torch.rand(48, 80, 3, generator=g) * 255).to(torch.uint8).numpy()
+            Image.fromarray(arr).save(os.path.join(root, "images", cls, name + ".png"))
+            with open(os.path.join(root, "annotations", name + ".xml"), "w") as f:
+                f.write(f"<annotation><size><width>80</width><height>48</height></size><object><bndbox><xmin>{5 + j}</xmin>"
+                        f"<ymin>{3 + ci}</ymin><xmax>{40 + j}</xmax><ymax>{30 + ci}</ymax></bndbox></object></annotation>")
+    keys = ("IMG_SIZE", "N_FEAT", "N_T", "BATCH_SIZE", "ACCUM_STEPS", "BOTTLENECK_K", "SAVE_DIR", "SAMPLE_DIR", "GUIDE_SCALES", "NUM_WORKERS")
+    saved = {k: getattr(Cfg, k) for k in keys}
+    try:
+        Cfg.IMG_SIZE, Cfg.N_FEAT, Cfg.N_T, Cfg.BATCH_SIZE, Cfg.ACCUM_STEPS, Cfg.BOTTLENECK_K, Cfg.NUM_WORKERS = 64, 32, 8, 4, 2, 4, 0
+        Cfg.SAVE_DIR, Cfg.SAMPLE_DIR, Cfg.GUIDE_SCALES = str(tmp_path / "ckpt") + "/", str(tmp_path / "samples") + "/", [2.0]
+        ddpm, hist = ns.train_model(max_epochs=1, quiet=True, data_root=root)
+        assert ddpm.n_classes == 2 and len(hist) == 1
+        assert torch.isfinite(torch.tensor(hist[0]["train_loss"])) and torch.isfinite(torch.tensor(hist[0]["val_loss"]))
+    finally:
+        for k, v in saved.items():
+            setattr(Cfg, k, v)
