@@ -170,7 +170,7 @@ def main():
     for i in range(args.steps):
         last = i == args.steps - 1 and not os.environ.get("DM_BENCH_NO_EVENTS")
         if last:
-            ops.PROFILE_KINDS = ("conv_igemm", "conv_wgrad") if dtype == torch.bfloat16 else ("igemm_f32", "wgrad_f32")
+            ops.PROFILE_KINDS = ("conv_igemm", "conv_halo", "conv_wgrad") if dtype == torch.bfloat16 else ("igemm_f32", "wgrad_f32")
             ops.PROFILE = []                   # (the instrumented step is launched eagerly: a replayed graph has no per-launch events)
         loss = train_step(eager=last)
     t_enq = time.perf_counter() - t0       # host time to enqueue the steps (the GPU runs behind it)
@@ -203,7 +203,10 @@ def main():
                 f.write(f"{sec / prof_steps * 1e3:8.3f} ms/step {n / prof_steps:5.1f}x {sec / n * 1e6:8.1f} us {flo / sec / 1e12:8.1f} TF/s  {kind:11s} {shape}\n")
     if dtype != torch.bfloat16:
         fl["conv_igemm"], fl["conv_wgrad"] = fl.get("igemm_f32", [0.0, 0.0, 0]), fl.get("wgrad_f32", [0.0, 0.0, 0])
-    dom = "conv_igemm"
+    # dominant kernel: conv3x3_halo_kernel (forward + input gradient of the 3x3 layers) when the run used it, else the gather kernel
+    fl.setdefault("conv_halo", [0.0, 0.0, 0])
+    dom = "conv_halo" if fl["conv_halo"][2] else "conv_igemm"
+    allconv = [fl["conv_igemm"][k] + fl["conv_halo"][k] for k in range(3)]
     peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
     ach = fl[dom][0] / max(fl[dom][1], 1e-12) / 1e12
     # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes over this same
@@ -216,17 +219,21 @@ def main():
             traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)"
     except (OSError, KeyError, ValueError):
         pass
-    roofline = {"bound": "mfma", "kernel": "dm_conv<%s> launches, fwd + dgrad (conv3x3_halo_kernel on the 3x3 layers, conv_igemm2_kernel elsewhere)" % args.dtype,
+    roofline = {"bound": "mfma", "kernel": ("conv3x3_halo_kernel<%s> (dm_conv forward + input-gradient launches of the 3x3 layers)" if dom == "conv_halo"
+                                            else "conv_igemm2_kernel<%s> (dm_conv forward + input-gradient launches)") % args.dtype,
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (avg)", "traffic_source": traffic_src,
-                "traffic_kernel": "conv3x3_halo_kernel (3/4 of the dm_conv bf16 time)",
+                "traffic_kernel": "conv3x3_halo_kernel",
                 "algorithmic_bytes_per_launch": "input read once + weights + output written once = 67-201 MB on the 64^2 layers, 34-50 MB on 32^2..8^2",
                 "launches": fl[dom][2], "avg_launch_us": round(fl[dom][1] / max(fl[dom][2], 1) * 1e6, 2),
                 "algorithmic_tflop_per_step": round(fl[dom][0] / prof_steps / 1e12, 4),
+                "all_dm_conv": {"achieved": round(allconv[0] / max(allconv[1], 1e-12) / 1e12, 2), "launches": allconv[2],
+                                "algorithmic_tflop_per_step": round(allconv[0] / prof_steps / 1e12, 4),
+                                "note": "every bf16 dm_conv launch of the step incl. 4x4/s2, 1x1 and ConvTranspose on the gather kernel"},
                 "wgrad": {"achieved": round(fl["conv_wgrad"][0] / max(fl["conv_wgrad"][1], 1e-12) / 1e12, 2),
                           "launches": fl["conv_wgrad"][2],
                           "algorithmic_tflop_per_step": round(fl["conv_wgrad"][0] / prof_steps / 1e12, 4)},
-                "mfma_time_share_of_step": round((fl["conv_igemm"][1] + fl["conv_wgrad"][1]) / prof_steps / (elapsed / args.steps), 4),
+                "mfma_time_share_of_step": round((allconv[1] + fl["conv_wgrad"][1]) / prof_steps / (elapsed / args.steps), 4),
                 "events": "HIP events on the launch stream around every MFMA launch of the last timed step"}
 
     # ---- CFG sampling rate (rank 0 only, not part of `value`)

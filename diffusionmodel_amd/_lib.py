@@ -92,7 +92,7 @@ _PROTOS = {
     "dm_randn_dev": [vp, i64, u64, vp],
     "dm_pack_multi": [vp, vp, vp, i32],
 }
-_NO_STREAM = {"dm_set_workspace": ([vp, i64], i32), "dm_set_conv_variant": ([i32], i32), "dm_set_wgrad_variant": ([i32], i32), "dm_version": ([], i32), "dm_last_error": ([], C.c_char_p), "dm_colstat_blocks": ([i32], i32)}
+_NO_STREAM = {"dm_last_conv_path": ([], i32), "dm_set_workspace": ([vp, i64], i32), "dm_set_conv_variant": ([i32], i32), "dm_set_wgrad_variant": ([i32], i32), "dm_version": ([], i32), "dm_last_error": ([], C.c_char_p), "dm_colstat_blocks": ([i32], i32)}
 
 EXPORTED = sorted(list(_PROTOS) + list(_NO_STREAM))
 

@@ -663,6 +663,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
     conv_epilogue<bf16, 128>(p, acc, smem + half * 4096, tidh, wm4 & 1, wn, fr, fg, mb * 2 + half, mw - (wm4 & 1) * 64, n0);
 }
 
+int g_last_path = 0;  // kernel family the last dm_conv launch used: 0 = gather (conv_igemm*), 1 = conv3x3_halo_kernel
+
 int g_variant = 5;    // 1 = register staging, 2..4 = LDS-DMA with that many ring stages (2 workgroups/CU at 2),
                       // 5 (default) = halo-resident kernel for eligible 3x3 layers, else LDS-DMA with 2 stages (4 on small grids)
 
@@ -714,6 +716,7 @@ int launch_halo(const ConvP& p, hipStream_t st) {
     }
     hipLaunchKernelGGL((conv3x3_halo_kernel<TW, FLIP>), dim3((unsigned)(tiles * q.splits)), dim3(512), HALO_LDS, st, q);
     DM_LAUNCH_CHECK();
+    g_last_path = 1;
     if (q.splits > 1) {
         hipLaunchKernelGGL((splitk_epilogue_kernel<bf16, 128>), dim3((unsigned)(tiles * 2)), dim3(256), 0, st, q);
         DM_LAUNCH_CHECK();
@@ -799,8 +802,11 @@ extern "C" int dm_set_conv_variant(int variant) {
     return DM_OK;
 }
 
+extern "C" int dm_last_conv_path(void) { return g_last_path; }
+
 extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
     DM_CHECK_ARG(d != nullptr, "dm_conv: null descriptor");
+    g_last_path = 0;
     const int ve = d->dtype == DM_BF16 ? 8 : 4;
     DM_CHECK_ARG(d->dtype == DM_F32 || d->dtype == DM_BF16, "dm_conv: bad dtype %d", d->dtype);
     DM_CHECK_ARG(d->in1 && d->w && d->out, "dm_conv: null tensor pointer");

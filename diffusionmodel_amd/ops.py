@@ -235,6 +235,8 @@ def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, s
         e0.record()
         call("dm_conv", C.byref(d))
         e1.record()
+        if kind == "conv_igemm" and L.load().dm_last_conv_path() == 1:
+            kind = "conv_halo"                # the launch went to conv3x3_halo_kernel
         PROFILE.append((kind, 2.0 * B * Hq * Wq * N * T * (C1 + C2), e0, e1,
                         f"B{B} {Hi}x{Wi} C{C1}+{C2} N{N} T{T} s{sy} t{ty} o{oy0} out{Ho}x{Wo}/{osy}"))
 

@@ -60,6 +60,8 @@ int dm_conv(const DmConv* d, dm_stream_t stream);
 /* tuning knob: staging pipeline of dm_conv — 1 = register staging, 2..4 = LDS-DMA gather ring with that many stages,
    5 (default) = halo-resident kernel for 3x3 stride-1 layers on 16/32/64-pixel rows with 64-channel multiples, gather ring otherwise */
 int dm_set_conv_variant(int variant);
+/* which kernel family the last dm_conv call launched: 0 = gather kernel (conv_igemm*), 1 = conv3x3_halo_kernel (profiling aid) */
+int dm_last_conv_path(void);
 
 /* Weight gradient of the same gather convolution (fp32 atomics into dw, which the caller zeroes or
  * accumulates into):  dw[n*ldw + t*C + c] += sum_m dy[orow(m)][n] * in(pix(m,t))[c],
