@@ -1,7 +1,12 @@
-// Implicit-GEMM gather convolution on the CDNA4 matrix cores (forward, input-gradient, ConvTranspose,
-// and — as a 1x1 "image" — the dense fp32 layers).
+// dm_conv: the convolutions of the denoiser on the CDNA4 matrix cores (forward, input-gradient, ConvTranspose,
+// and — as a 1x1 "image" — the dense fp32 layers).  Two kernel families:
 //
-// One kernel family serves every dense contraction of the denoiser (include/dm_amd.h, dm_conv): the
+//   * conv3x3_halo_kernel (further down): the 3x3 stride-1 layers — 93 % of the FLOPs — with the input halo of a
+//     256-pixel tile resident in LDS and only the weights streaming; split-K through the workspace for few-tile /
+//     deep-K layers.  Its header comment explains why the gather form is L2->LDS-fill-bound on these layers.
+//   * the gather kernels described here: everything else (4x4 stride 2, 1x1, ConvTranspose, dense layers, odd sizes).
+//
+// Gather kernels (include/dm_amd.h, dm_conv): the
 // output tile is 128 output pixels x BN output channels per 256-thread workgroup (4 waves as 2(m) x 2(n)),
 // K runs over taps x input channels in steps of 128 bytes per row (64 bf16 / 32 f32 channels).  Both
 // operands are staged in LDS as [row][128 B] images whose 16-byte vectors are XOR-swizzled with the row
@@ -9,7 +14,8 @@
 // instruction hits 16 distinct 16-B slots of the 256-B bank row).
 //
 // Two staging pipelines:
-//   v2 (default) LDS-DMA: `global_load_lds_dwordx4` writes the stage directly (no VGPR round trip, no
+//   v2 LDS-DMA (2-stage ring; 4 stages when the grid does not fill the chip; split-K through the workspace when a handful
+//      of tiles share a long reduction): `global_load_lds_dwordx4` writes the stage directly (no VGPR round trip, no
 //      ds_write, almost no per-step address arithmetic: per-lane row offsets and a per-row tap-validity
 //      bitmask are computed once, a k-step costs one add + one select per 1-KiB piece).  The LDS image
 //      is lane-linear per wave-instruction (8 rows x 8 vectors), so the swizzle sits on the SOURCE

@@ -2,6 +2,9 @@
 //
 //   dw[n][t][c] += sum_m dy[orow(m)][n] * in(pix(m,t))[c]
 //
+// Two kernel families: wgrad3x3_halo_kernel (further down) for the 3x3 stride-1 layers — all nine taps from one staged
+// input halo, split partials through the workspace — and the per-tap kernels described here for everything else.
+//
 // GEMM view per tap t: D[i = n][j = c], reduction index k = output pixel m.  In NHWC memory the
 // reduction index is the SLOW index of both operands (rows are pixels), while an MFMA fragment wants
 // consecutive k per lane, so both operands are staged as [pixel][channel] images in LDS and read
