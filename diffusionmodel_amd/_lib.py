@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdm_amd.so")
+LIB_PATH = os.environ.get("DM_LIB_PATH") or os.path.join(_HERE, "libdm_amd.so")     # (DM_LIB_PATH: experimental builds)
 DEFAULT_CONV_VARIANT = 5      # what libdm_amd.so starts with (igemm.hip g_variant); DM_CONV_VARIANT overrides
 
 DM_F32, DM_BF16 = 0, 1
