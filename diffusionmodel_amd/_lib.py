@@ -85,8 +85,10 @@ _PROTOS = {
     "dm_loss_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32],
     "dm_loss_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32],
     "dm_cfg_update": [vp, vp, vp, f32, vp, vp, vp, vp, u64, i64, i32],
+    "dm_cfg_update_slice": [vp, vp, vp, f32, vp, vp, vp, vp, u64, i64, i64, i32],
     "dm_fill_t": [vp, vp, i32, i32],
     "dm_randn": [vp, i64, u64, u64],
+    "dm_randn_slice": [vp, i64, u64, u64, i64],
     "dm_sumsq": [vp, i64, vp],
     "dm_adamw": [vp, vp, vp, vp, i64, vp, vp, vp, vp],
     "dm_randn_dev": [vp, i64, u64, vp],

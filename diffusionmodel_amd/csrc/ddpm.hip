@@ -34,12 +34,12 @@ __device__ inline void normal4(uint64_t seed, uint64_t ctr_hi, uint64_t ctr_lo, 
     box_muller(r.z, r.w, z[2], z[3]);
 }
 
-__global__ void randn_kernel(float* out, int64_t n, uint64_t seed, uint64_t offset, const uint64_t* offset_dev) {
+__global__ void randn_kernel(float* out, int64_t n, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int64_t first_quad) {
     if (offset_dev) offset = *offset_dev;              // stream offset kept on the device (hipGraph replays advance it)
     const int64_t n4 = (n + 3) / 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float z[4];
-        normal4(seed, offset, (uint64_t)i, z);
+        normal4(seed, offset, (uint64_t)(first_quad + i), z);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (i * 4 + k < n) out[i * 4 + k] = z[k];
@@ -128,13 +128,13 @@ __global__ void loss_bwd_kernel(const float* pred, const float* noise, const flo
 
 // ---- CFG combine + ancestral update ------------------------------------------------------------
 __global__ void cfg_update_kernel(float* x, const float* eps2n, const float* z, float gw, const float* a_t, const float* b_t,
-                                  const float* s_t, const int32_t* step, uint64_t seed, int64_t n) {
+                                  const float* s_t, const int32_t* step, uint64_t seed, int64_t n, int64_t first_quad) {
     const int i_t = step[0];
     const float a = a_t[i_t], bb = b_t[i_t], sg = i_t > 1 ? s_t[i_t] : 0.f;
     const int64_t n4 = (n + 3) / 4;
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
         float zz[4] = {0.f, 0.f, 0.f, 0.f};
-        if (i_t > 1 && !z) normal4(seed, (uint64_t)i_t, (uint64_t)q, zz);
+        if (i_t > 1 && !z) normal4(seed, (uint64_t)i_t, (uint64_t)(first_quad + q), zz);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int64_t i = q * 4 + k;
@@ -222,14 +222,21 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
 
 extern "C" int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, dm_stream_t s) {
     DM_CHECK_ARG(out && n > 0, "dm_randn: bad arguments");
-    hipLaunchKernelGGL(randn_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, ST, out, n, seed, offset, (const uint64_t*)nullptr);
+    hipLaunchKernelGGL(randn_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, ST, out, n, seed, offset, (const uint64_t*)nullptr, (int64_t)0);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_randn_slice(float* out, int64_t n, uint64_t seed, uint64_t offset, int64_t first_elem, dm_stream_t s) {
+    DM_CHECK_ARG(out && n > 0 && first_elem >= 0 && first_elem % 4 == 0, "dm_randn_slice: bad arguments (first_elem must be a multiple of 4)");
+    hipLaunchKernelGGL(randn_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, ST, out, n, seed, offset, (const uint64_t*)nullptr, first_elem / 4);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
 
 extern "C" int dm_randn_dev(float* out, int64_t n, uint64_t seed, const uint64_t* offset_dev, dm_stream_t s) {
     DM_CHECK_ARG(out && n > 0 && offset_dev, "dm_randn_dev: bad arguments");
-    hipLaunchKernelGGL(randn_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, ST, out, n, seed, (uint64_t)0, offset_dev);
+    hipLaunchKernelGGL(randn_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, ST, out, n, seed, (uint64_t)0, offset_dev, (int64_t)0);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
@@ -258,14 +265,21 @@ extern "C" int dm_loss_bwd(const float* pred, const float* noise, const float* m
     return DM_OK;
 }
 
-extern "C" int dm_cfg_update(float* x, const float* eps2n, const float* z, float guide_w, const float* oneover_sqrta,
-                             const float* mab_over_sqrtmab, const float* sqrt_beta_t, int32_t* step, uint64_t seed, int64_t n_elems,
-                             int dec_step, dm_stream_t s) {
+extern "C" int dm_cfg_update_slice(float* x, const float* eps2n, const float* z, float guide_w, const float* oneover_sqrta,
+                                   const float* mab_over_sqrtmab, const float* sqrt_beta_t, int32_t* step, uint64_t seed, int64_t n_elems,
+                                   int64_t first_elem, int dec_step, dm_stream_t s) {
     DM_CHECK_ARG(x && eps2n && oneover_sqrta && mab_over_sqrtmab && sqrt_beta_t && step && n_elems > 0, "dm_cfg_update: bad arguments");
-    hipLaunchKernelGGL(cfg_update_kernel, dim3(grid_for((n_elems + 3) / 4, 256)), dim3(256), 0, ST, x, eps2n, z, guide_w, oneover_sqrta, mab_over_sqrtmab, sqrt_beta_t, step, seed, n_elems);
+    DM_CHECK_ARG(first_elem >= 0 && first_elem % 4 == 0, "dm_cfg_update_slice: first_elem must be a non-negative multiple of 4");
+    hipLaunchKernelGGL(cfg_update_kernel, dim3(grid_for((n_elems + 3) / 4, 256)), dim3(256), 0, ST, x, eps2n, z, guide_w, oneover_sqrta, mab_over_sqrtmab, sqrt_beta_t, step, seed, n_elems, first_elem / 4);
     if (dec_step) hipLaunchKernelGGL(dec_step_kernel, dim3(1), dim3(64), 0, ST, step);
     DM_LAUNCH_CHECK();
     return DM_OK;
+}
+
+extern "C" int dm_cfg_update(float* x, const float* eps2n, const float* z, float guide_w, const float* oneover_sqrta,
+                             const float* mab_over_sqrtmab, const float* sqrt_beta_t, int32_t* step, uint64_t seed, int64_t n_elems,
+                             int dec_step, dm_stream_t s) {
+    return dm_cfg_update_slice(x, eps2n, z, guide_w, oneover_sqrta, mab_over_sqrtmab, sqrt_beta_t, step, seed, n_elems, 0, dec_step, s);
 }
 
 extern "C" int dm_fill_t(float* t, const int32_t* step, int n_T, int B, dm_stream_t s) {

@@ -115,21 +115,35 @@ class DDPM(_HipBlock):
 
     @torch.no_grad()
     def sample(self, n_sample, size, device, guide_w=0.0, refine_steps=2, *, x_T=None, zs=None, dedup=True,
-               use_graph=False, seed=None, steps=None, verbose=False):
+               use_graph=False, seed=None, steps=None, verbose=False, first_sample=0, total_samples=None):
         """Ancestral sampling with doubled-batch CFG (new_scripy.py:441-477).  `refine_steps` is unused, as in the
         reference.  The guidance convention is the reference's: the first half of the doubled batch has
         ctx_mask 0, so eps = (1+w)*eps_uncond - w*eps_cond.
 
         x_T / zs inject the initial noise and the per-step noise (zs[j] is used at step i = n_T - j);
         otherwise Philox noise is generated in-kernel.  use_graph captures one step as a hipGraph and
-        replays it (requires in-kernel noise).  `steps` stops after that many iterations (tests)."""
+        replays it (requires in-kernel noise).  `steps` stops after that many iterations (tests).
+
+        first_sample / total_samples (parallel.sample_sharded): this call produces samples [first_sample, first_sample +
+        n_sample) of a class-cycled batch of total_samples — their classes and their slice of the in-kernel noise
+        stream — so the shards of any world size concatenate to the images of the single-process call with that seed."""
         net = self.nn_model
-        if n_sample % self.n_classes:
-            raise DmError(f"n_sample={n_sample} must be a multiple of n_classes={self.n_classes} (new_scripy.py:448)")
+        total = n_sample if total_samples is None else int(total_samples)
+        if total % self.n_classes:
+            raise DmError(f"n_sample={total} must be a multiple of n_classes={self.n_classes} (new_scripy.py:448)")
+        if first_sample < 0 or first_sample + n_sample > total:
+            raise DmError(f"samples [{first_sample}, {first_sample + n_sample}) are not inside a batch of {total}")
         dev = torch.device(device)
         seed = self._seed() if seed is None else int(seed)
-        x_i = (x_T.to(dev).float().contiguous().clone() if x_T is not None else ops.randn((n_sample,) + tuple(size), dev, seed, 0))
-        c_i = torch.arange(0, self.n_classes, device=dev).repeat(n_sample // self.n_classes).repeat(2)
+        per = 1
+        for d in size:
+            per *= int(d)
+        first_elem = first_sample * per
+        if first_elem % 4:
+            raise DmError(f"a shard must start on a multiple of 4 elements (first_sample={first_sample}, {per} elements per sample)")
+        x_i = (x_T.to(dev).float().contiguous().clone() if x_T is not None
+               else ops.randn((n_sample,) + tuple(size), dev, seed, 0, first_elem))
+        c_i = ((first_sample + torch.arange(0, n_sample, device=dev)) % self.n_classes).repeat(2)      # arange(n_classes).repeat(..) (:448)
         mask = torch.zeros(2 * n_sample, device=dev)
         mask[n_sample:] = 1.0
         oh = ops.onehot_mask(c_i, mask, self.n_classes)
@@ -142,7 +156,7 @@ class DDPM(_HipBlock):
         def one_step(z):
             ops.fill_t(t2, step, self.n_T)
             eps = self._eps_cfg(x_i, c_i, mask, t2, ctx_embs, dedup)
-            ops.cfg_update(x_i, eps, z, guide_w, sched, step, seed=seed, dec_step=True)
+            ops.cfg_update(x_i, eps, z, guide_w, sched, step, seed=seed, dec_step=True, first_elem=first_elem)
 
         if use_graph:
             if zs is not None:

@@ -998,23 +998,27 @@ class WeightedLoss(torch.autograd.Function):
         return dpred, None, None, None
 
 
-def cfg_update(x, eps2n, z, guide_w, sched, step, seed=0, dec_step=True):
-    """In-place x_{t-1} update (new_scripy.py:468-475); `step` is a device int32 tensor holding i."""
-    call("dm_cfg_update", ptr(x), ptr(eps2n), ptr(z), float(guide_w), ptr(sched["oneover_sqrta"]), ptr(sched["mab_over_sqrtmab"]),
-         ptr(sched["sqrt_beta_t"]), ptr(step), int(seed), x.numel(), int(dec_step))
+def cfg_update(x, eps2n, z, guide_w, sched, step, seed=0, dec_step=True, first_elem=0):
+    """In-place x_{t-1} update (new_scripy.py:468-475); `step` is a device int32 tensor holding i.  `first_elem`: x is the
+    slice starting at that element of a larger batch (sharded sampling draws the matching slice of the noise stream)."""
+    call("dm_cfg_update_slice", ptr(x), ptr(eps2n), ptr(z), float(guide_w), ptr(sched["oneover_sqrta"]), ptr(sched["mab_over_sqrtmab"]),
+         ptr(sched["sqrt_beta_t"]), ptr(step), int(seed), x.numel(), int(first_elem), int(dec_step))
 
 
 def fill_t(t, step, n_T):
     call("dm_fill_t", ptr(t), ptr(step), int(n_T), t.numel())
 
 
-def randn(shape, device, seed, offset):
-    """Philox N(0,1); `offset` is a Python int, or a device int64 tensor that is read when the kernel runs."""
+def randn(shape, device, seed, offset, first_elem=0):
+    """Philox N(0,1); `offset` is a Python int, or a device int64 tensor that is read when the kernel runs.
+    `first_elem` (multiple of 4): the result is elements [first_elem, first_elem + numel) of the stream."""
     out = torch.empty(shape, dtype=torch.float32, device=device)
     if isinstance(offset, torch.Tensor):
+        if first_elem:
+            raise L.DmError("randn: a device-resident offset cannot be combined with first_elem")
         call("dm_randn_dev", ptr(out), out.numel(), int(seed), ptr(offset))
     else:
-        call("dm_randn", ptr(out), out.numel(), int(seed), int(offset))
+        call("dm_randn_slice", ptr(out), out.numel(), int(seed), int(offset), int(first_elem))
     return out
 
 

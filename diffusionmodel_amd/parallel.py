@@ -15,6 +15,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from ._lib import DmError
+
 
 def init_from_env(backend=None, force=False):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
@@ -244,3 +246,26 @@ def broadcast_parameters(flat_params, src=0, group=None):
     """Identical initial weights on every rank."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat_params, src=src, group=group)
+
+
+def sample_sharded(ddpm, n_sample, size, device, guide_w=0.0, *, group=None, gather=True, **kw):
+    """CFG sampling sharded over the ranks (samples are independent, no exchange inside the trajectory).
+
+    Rank r runs `ddpm.sample` on samples [r m, (r + 1) m), m = n_sample / world, of the class-cycled batch with their slice of
+    the Philox noise stream; one all-gather at the end returns the (n_sample, *size) images on every rank (gather=False: the
+    local shard only).  Same seed on every rank -> the result does not depend on the world size (eval-mode BatchNorm is
+    per-sample; only the split-K summation order of a few layers follows the batch size)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if n_sample % world:
+        raise DmError(f"n_sample={n_sample} does not shard over {world} ranks")
+    if kw.get("seed") is None:
+        raise DmError("sample_sharded needs an explicit seed= (identical on every rank)")
+    m = n_sample // world
+    x = ddpm.sample(m, size, device, guide_w, first_sample=rank * m, total_samples=n_sample, **kw)
+    if world == 1 or not gather:
+        return x
+    out = torch.empty((n_sample,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    return out
+

@@ -226,10 +226,17 @@ int dm_loss_bwd(const float* pred, const float* noise, const float* mask, const 
 int dm_cfg_update(float* x, const float* eps2n, const float* z, float guide_w, const float* oneover_sqrta,
                   const float* mab_over_sqrtmab, const float* sqrt_beta_t, int32_t* step, uint64_t seed, int64_t n_elems,
                   int dec_step, dm_stream_t s);
+/* the same update on elements [first_elem, first_elem + n_elems) of a larger batch: the in-kernel noise is the slice of the
+ * whole batch's Philox stream, so sampling sharded over ranks reproduces the single-process images (sampling) */
+int dm_cfg_update_slice(float* x, const float* eps2n, const float* z, float guide_w, const float* oneover_sqrta,
+                        const float* mab_over_sqrtmab, const float* sqrt_beta_t, int32_t* step, uint64_t seed, int64_t n_elems,
+                        int64_t first_elem, int dec_step, dm_stream_t s);
 /* t[b] = *step / n_T for b < B (feeds the time embedding inside a captured loop) */
 int dm_fill_t(float* t, const int32_t* step, int n_T, int B, dm_stream_t s);
 /* N(0,1) fill by Philox4x32-10 (used for noise when the caller does not inject it) */
 int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, dm_stream_t s);
+/* elements [first_elem, first_elem + n) of that stream (first_elem a multiple of 4) */
+int dm_randn_slice(float* out, int64_t n, uint64_t seed, uint64_t offset, int64_t first_elem, dm_stream_t s);
 /* same stream, the offset read from device memory at execution time (a captured hipGraph draws fresh noise every replay) */
 int dm_randn_dev(float* out, int64_t n, uint64_t seed, const uint64_t* offset_dev, dm_stream_t s);
 

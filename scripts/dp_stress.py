@@ -1,10 +1,8 @@
-"""Rehearsal of the data-parallel step on ONE GPU: 2 ranks (torchrun --nproc-per-node 2), both on cuda:0, gloo backend
-(RCCL refuses two ranks per device).  It exercises what the CPU tests cannot: OverlappedGradReducer driven by the real
-backward pass (ON_WGRAD notifications from the HIP weight-gradient launches, side stream, packed `.grad` reduce), and
-checks the reduced gradient of the observation step and of two overlapped steps against a blocking host-side sum of the
-ranks' local gradients, parameter by parameter.
+"""Diagnosis aid for the one-GPU two-rank rehearsal (scripts/dp_rehearsal.py): repeats the local backward pass and the reduced
+backward pass and reports, per repetition, (a) how far a LOCAL gradient is from the first local one (kernel nondeterminism) and
+(b) how far the REDUCED gradient is from the host-side sum — so that a mismatch can be attributed to the kernels or to the reducer.
 
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29631 scripts/dp_rehearsal.py
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29641 scripts/dp_stress.py [reps]
 """
 import os
 import sys
@@ -22,12 +20,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import diffusionmodel_amd as D
 from diffusionmodel_amd import parallel
 
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 dist.init_process_group("gloo", rank=rank, world_size=world)
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
-
 torch.manual_seed(0)
 net = D.ContextUnet(3, 64, 4, bottleneck_k=4, dtype=torch.bfloat16)
 ddpm = D.DDPM(net, (1e-4, 0.02), 1000, dev, drop_prob=0.1)
@@ -42,8 +40,7 @@ am = torch.ones(8, 64, 64, device=dev)
 red = parallel.OverlappedGradReducer(opt, n_buckets=5)
 
 
-def backward_only(reducer):
-    """One forward/backward with identical random draws every call; returns the flat gradient after reduction (or the local one)."""
+def run(reducer):
     torch.manual_seed(7 + rank)
     ddpm._rng_calls = 0
     ddpm._rng_dev = None
@@ -52,31 +49,35 @@ def backward_only(reducer):
         reducer.begin()
     loss = ddpm(x, c, am)
     loss.backward()
-    early = sum(reducer._launched) if reducer is not None else 0
     if reducer is not None:
         reducer.finish()
     else:
         opt.gather_grads()
     torch.cuda.synchronize()
-    return opt.flat_g.clone(), float(loss), early
+    return opt.flat_g.clone()
 
 
-local, l0, _ = backward_only(None)
-ref = local.cpu()
-dist.all_reduce(ref)                                   # blocking host-side sum of the ranks' local gradients
-ref = ref.to(dev)
-worst = 0.0
-for step in range(3):                                  # step 0 = observation (no early launches), 1-2 overlapped
-    got, l1, early = backward_only(red)
-    rel = ((got - ref).norm() / ref.norm()).item()
+def worst(got, ref):
     bad = []
     for (p, off, n), name in zip(opt._slots, names):
-        d = (got[off:off + n] - ref[off:off + n]).norm().item() / max(ref[off:off + n].norm().item(), 1e-30)
-        if d > 1e-3 and ref[off:off + n].norm().item() > 1e-12:
-            bad.append((name, d))
-    print(f"rank {rank} step {step}: loss {l1:.5f} (local run {l0:.5f}), buckets launched during backward {early}/{len(red.buckets)}, "
-          f"|reduced - host sum| / |host sum| = {rel:.2e}, parameters off by > 1e-3: {len(bad)} {bad[:3]}")
-    worst = max(worst, rel)
-    assert (early == 0) == (step == 0), early
-assert worst < 1e-5, worst                            # only fp32 atomic ordering of the non-halo weight-gradient kernels differs
+        rn = ref[off:off + n].norm().item()
+        if rn > 1e-9:
+            d = (got[off:off + n] - ref[off:off + n]).norm().item() / rn
+            if d > 1e-3:
+                bad.append((name, round(d, 4)))
+    return bad
+
+
+local0 = run(None)
+ref = local0.cpu()
+dist.all_reduce(ref)
+ref = ref.to(dev)
+for r in range(reps):
+    loc = run(None)
+    dl = ((loc - local0).norm() / local0.norm()).item()
+    got = run(red)
+    dr = ((got - ref).norm() / ref.norm()).item()
+    bl, br = worst(loc, local0), worst(got, ref)
+    print(f"rank {rank} rep {r}: local vs first local {dl:.2e} ({len(bl)} params > 1e-3: {bl[:4]}); reduced vs host sum {dr:.2e} "
+          f"({len(br)} params > 1e-3: {br[:4]})", flush=True)
 dist.destroy_process_group()

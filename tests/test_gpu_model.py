@@ -442,7 +442,9 @@ def test_graphed_train_step_matches_eager_and_leaves_state_alone():
 
 def test_overlapped_gradient_reducer_two_ranks_on_one_gpu():
     """scripts/dp_rehearsal.py: two gloo ranks sharing cuda:0 run the real backward pass through OverlappedGradReducer
-    (observation step + two overlapped steps) and compare the reduced flat gradient with a blocking host-side sum."""
+    (observation step + two overlapped steps) and compare the reduced flat gradient with a blocking host-side sum.
+    The script pins the <= 64-KiB-LDS kernel variants: workgroups with more LDS do not survive preemption between
+    processes that time-share one GPU on this stack (multi-GPU section)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -452,3 +454,30 @@ def test_overlapped_gradient_reducer_two_ranks_on_one_gpu():
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "step 2" in r.stdout and "4/4" in r.stdout, r.stdout[-1500:]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 0.25)])
+def test_sample_shards_concatenate_to_single_call(dtype, tol):
+    """samples [a, b) of the class-cycled batch, drawn with their slice of the Philox stream, equal
+    rows [a, b) of the single call — what parallel.sample_sharded runs on each rank.  fp32: only the summation order of the
+    batch-size-dependent split-K layers differs; bf16: a rounding flip in one layer propagates (loose bar, exact noise)."""
+    import diffusionmodel_amd as D
+    from diffusionmodel_amd import parallel
+    torch.manual_seed(3)
+    net = D.ContextUnet(3, 32, 4, bottleneck_k=4, dtype=dtype)
+    ddpm = D.DDPM(net, (1e-4, 0.02), 50, DEV, drop_prob=0.1)
+    ddpm.eval()
+    kw = dict(guide_w=2.0, seed=77, steps=6)
+    full = ddpm.sample(8, (3, 64, 64), DEV, **kw)
+    lo = ddpm.sample(4, (3, 64, 64), DEV, first_sample=0, total_samples=8, **kw)
+    hi = ddpm.sample(4, (3, 64, 64), DEV, first_sample=4, total_samples=8, use_graph=True, **kw)
+    odd = ddpm.sample(2, (3, 64, 64), DEV, first_sample=5, total_samples=8, **kw)          # a shard need not start on a class boundary
+    assert torch.isfinite(full).all() and full.std() > 0.1
+    assert (torch.cat([lo, hi]) - full).abs().max().item() < tol
+    assert (odd - full[5:7]).abs().max().item() < tol
+    assert not torch.allclose(lo, hi)
+    one = parallel.sample_sharded(ddpm, 8, (3, 64, 64), DEV, **kw)                          # no process group: one shard
+    assert (one - full).abs().max().item() < tol
+    with pytest.raises(D.DmError):
+        ddpm.sample(4, (3, 64, 64), DEV, first_sample=6, total_samples=8, **kw)
+

@@ -230,3 +230,43 @@ def test_gloo_overlapped_reducer_equals_plain_sum(tmp_path):
     got1, loc1 = torch.load(os.path.join(str(tmp_path), "ov_1.pt"))
     assert torch.equal(got0, got1)
     assert torch.allclose(got0, loc0 + loc1, rtol=0, atol=1e-6)
+
+
+# ---- sharded sampling: slices of the class-cycled batch, one all-gather, rank order ------------------------------------
+class _StubSampler:
+    """Stands in for DDPM.sample on the CPU: encodes (global sample index, class) in the image it returns."""
+    n_classes = 4
+
+    def sample(self, n_sample, size, device, guide_w=0.0, *, first_sample=0, total_samples=None, seed=None, **kw):
+        assert total_samples % self.n_classes == 0 and seed == 11
+        idx = first_sample + torch.arange(n_sample)
+        img = torch.zeros((n_sample,) + tuple(size))
+        img[:, 0] = idx.float().view(-1, 1, 1)
+        img[:, 1] = (idx % self.n_classes).float().view(-1, 1, 1)
+        img[:, 2] = guide_w
+        return img
+
+
+def _sample_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    parallel.init_from_env("gloo")
+    full = parallel.sample_sharded(_StubSampler(), 8, (3, 4, 4), "cpu", 2.0, seed=11)
+    local = parallel.sample_sharded(_StubSampler(), 8, (3, 4, 4), "cpu", 2.0, seed=11, gather=False)
+    with pytest.raises(parallel.DmError):
+        parallel.sample_sharded(_StubSampler(), 9, (3, 4, 4), "cpu", 2.0, seed=11)      # does not shard over 2 ranks
+    with pytest.raises(parallel.DmError):
+        parallel.sample_sharded(_StubSampler(), 8, (3, 4, 4), "cpu", 2.0)               # every rank must use the same seed
+    torch.save((full, local), os.path.join(out_dir, f"smp_{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_sharded_sampling_gathers_in_rank_order(tmp_path):
+    import torch.multiprocessing as mp
+    world, port = 2, 33000 + os.getpid() % 2000
+    mp.spawn(_sample_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    want = _StubSampler().sample(8, (3, 4, 4), "cpu", 2.0, total_samples=8, seed=11)
+    for r in range(world):
+        full, local = torch.load(os.path.join(str(tmp_path), f"smp_{r}.pt"))
+        assert torch.equal(full, want)
+        assert torch.equal(local, want[r * 4:(r + 1) * 4])
+
