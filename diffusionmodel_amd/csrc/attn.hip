@@ -12,11 +12,17 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 template <typename T, int V, int MODE>
 __global__ __launch_bounds__(256) void strip_reduce_kernel(const T* x, const T* y, float* out, int A, int R, int sa, int sr,
-                                                           int P /*pixels per sample*/, int C, float scale) {
+                                                           int P /*pixels per sample*/, int C, float scale, int RS, int rps) {
+    // RS > 1: the R positions are split over RS workgroups (rps each); workgroup (strip, rs) writes its partial sums to
+    // out[rs][strip][c] (a scratch array, scale 1) and strip_fold_kernel adds them up — a whole-image pool (A = 1, R = H*W) on
+    // B workgroups left 3/4 of the chip idle and ran a 256-deep serial load chain per thread (142 us for 67 MB)
     __shared__ float red[2048];
-    const int b = blockIdx.x / A, a = blockIdx.x - b * A;
+    const int strip = blockIdx.x / RS, rs = blockIdx.x - strip * RS;
+    const int b = strip / A, a = strip - b * A;
+    const int r_lo = rs * rps, r_hi = min(R, r_lo + rps);
     const int CVt = (C + V - 1) / V;
     const size_t base = ((size_t)b * P + (size_t)a * sa) * C;
+    out += (size_t)rs * (gridDim.x / RS) * C;
     for (int cbase = 0; cbase < CVt; cbase += 256) {
         const int ncv = min(256, CVt - cbase);
         const int RL = 256 / ncv;
@@ -26,7 +32,7 @@ __global__ __launch_bounds__(256) void strip_reduce_kernel(const T* x, const T* 
         for (int i = 0; i < V; ++i) acc[i] = 0.f;
         if (rl < RL) {
             const int c0 = (cbase + cv) * V;
-            for (int r = rl; r < R; r += RL) {
+            for (int r = r_lo + rl; r < r_hi; r += RL) {
                 float v[V];
                 const size_t off = base + (size_t)r * sr * C + c0;
                 if constexpr (V == 1) v[0] = Elem<T>::ld(x + off); else load_vec<T>(x + off, v);
@@ -56,16 +62,37 @@ __global__ __launch_bounds__(256) void strip_reduce_kernel(const T* x, const T* 
     }
 }
 
+// out[j] = scale * sum_rs part[rs][j]
+__global__ void strip_fold_kernel(const float* part, float* out, int n, int RS, float scale) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < RS; ++k) s += part[(size_t)k * n + j];
+    out[j] = s * scale;
+}
+
 template <int MODE>
 int launch_strip(const void* x, const void* y, float* out, int dtype, int B, int A, int R, int sa, int sr, int P, int C, float scale,
                  hipStream_t st) {
+    // few long strips (the whole-image pools of the SE block): split the positions until ~1024 workgroups share the read
+    int RS = 1, rps = R;
+    if (B * A < 512 && R >= 256 && dm_g_ws != nullptr) {
+        RS = 1024 / (B * A);
+        if (RS > R / 64) RS = R / 64;
+        if (RS < 1 || (int64_t)RS * B * A * C * (int64_t)sizeof(float) > dm_g_ws_bytes) RS = 1;
+        rps = cdiv(R, RS);
+        RS = cdiv(R, rps);
+    }
+    float* dst = RS > 1 ? dm_g_ws : out;
+    const float sc = RS > 1 ? 1.f : scale;
     DM_DISPATCH_DTYPE(dtype, {
         const uintptr_t m = (uintptr_t)x | (uintptr_t)y;
         if (C % Elem<T>::VE == 0 && (m & 15) == 0)
-            hipLaunchKernelGGL((strip_reduce_kernel<T, Elem<T>::VE, MODE>), dim3(B * A), dim3(256), 0, st, (const T*)x, (const T*)y, out, A, R, sa, sr, P, C, scale);
+            hipLaunchKernelGGL((strip_reduce_kernel<T, Elem<T>::VE, MODE>), dim3(B * A * RS), dim3(256), 0, st, (const T*)x, (const T*)y, dst, A, R, sa, sr, P, C, sc, RS, rps);
         else
-            hipLaunchKernelGGL((strip_reduce_kernel<T, 1, MODE>), dim3(B * A), dim3(256), 0, st, (const T*)x, (const T*)y, out, A, R, sa, sr, P, C, scale);
+            hipLaunchKernelGGL((strip_reduce_kernel<T, 1, MODE>), dim3(B * A * RS), dim3(256), 0, st, (const T*)x, (const T*)y, dst, A, R, sa, sr, P, C, sc, RS, rps);
     });
+    if (RS > 1) hipLaunchKernelGGL(strip_fold_kernel, dim3(cdiv(B * A * C, 256)), dim3(256), 0, st, dm_g_ws, out, B * A * C, RS, scale);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
@@ -373,8 +400,20 @@ extern "C" int dm_sigmix_bwd(const float* dxo, const float* y, const float* gamm
     return DM_OK;
 }
 
+// dense.hip: the MFMA kernels for vector-width shapes
+int dm_dense_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act, hipStream_t st);
+int dm_dense_bwd(const float* x, const float* w, const float* gy, float* dx, float* dw, float* db, int M, int K, int N, hipStream_t st);
+static inline bool dense_ok(int K, int N, const void* a, const void* b, const void* c, const void* d) {
+    return K % 4 == 0 && N % 4 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) == 0;
+}
+
 extern "C" int dm_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act, dm_stream_t s) {
     DM_CHECK_ARG(x && w && y && M > 0 && K > 0 && N > 0, "dm_linear_fwd: bad arguments");
+    if (dense_ok(K, N, x, w, y, nullptr)) {
+        dm_dense_fwd(x, w, b, y, M, K, N, act, ST);
+        DM_LAUNCH_CHECK();
+        return DM_OK;
+    }
     hipLaunchKernelGGL(sgemm_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, ST, x, w, b, y, M, N, K, (int64_t)K, (int64_t)1, (int64_t)1, (int64_t)K, N, act, 0);
     DM_LAUNCH_CHECK();
     return DM_OK;
@@ -383,6 +422,11 @@ extern "C" int dm_linear_fwd(const float* x, const float* w, const float* b, flo
 extern "C" int dm_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int M, int K, int N,
                              dm_stream_t s) {
     DM_CHECK_ARG(x && w && dy && M > 0 && K > 0 && N > 0, "dm_linear_bwd: bad arguments");
+    if (dense_ok(K, N, x, w, dy, dx) && (((uintptr_t)dw) & 15) == 0 && (dw || !db)) {
+        dm_dense_bwd(x, w, dy, dx, dw, db, M, K, N, ST);
+        DM_LAUNCH_CHECK();
+        return DM_OK;
+    }
     if (dx)  // dx[m][k] = sum_n dy[m][n] w[n][k]
         hipLaunchKernelGGL(sgemm_kernel, dim3(cdiv(K, 64), cdiv(M, 64)), dim3(256), 0, ST, dy, w, (const float*)nullptr, dx, M, K, N, (int64_t)N, (int64_t)1, (int64_t)K, (int64_t)1, K, 0, 0);
     if (dw)  // dw[n][k] += sum_m dy[m][n] x[m][k]

@@ -114,16 +114,47 @@ struct BnParams {
 };
 
 // one wave per channel: lanes stride over the partial blocks
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* psum, const float* psq, int nblk, int M, int C,
-                                                          float eps, float mom, float* mean, float* rstd, float* rmean,
-                                                          float* rvar) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = lane; b < nblk; b += 64) { s1 += (double)psum[(size_t)b * C + c]; s2 += (double)psq[(size_t)b * C + c]; }
+// Column sums over the per-block partial rows (nblk x C, up to 2048 rows on the 64x64 layers).  A 1024-thread workgroup owns
+// 16 columns: thread = (column, one of 64 row lanes), so a 16-lane group reads one 64-byte line per row (a wave-load touches 4
+// lines, not 64 as with a wave per column: that form spent 21 us on a 2048 x 128 array in the texture path alone) and every
+// thread has 16 independent loads in flight.  Row lanes fold in a fixed order (shuffles, then 16 per-wave values through LDS):
+// deterministic, fp64 accumulation.
+__device__ __forceinline__ double colsum16(const float* __restrict__ part, int nblk, int C, int c, bool ok, double* red) {
+    const int rl = threadIdx.x >> 4;
+    double s = 0.0;
+    if (ok) {
+        int b = rl;
+        for (; b + 64 * 7 < nblk; b += 64 * 8) {
+            float v[8];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-    if (lane == 0) {
+            for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(b + 64 * j) * C + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (double)v[j];
+        }
+        for (; b < nblk; b += 64) s += (double)part[(size_t)b * C + c];
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const int wave = threadIdx.x >> 6, col = threadIdx.x & 15;
+    __syncthreads();                                   // `red` may still be read from a previous call
+    if ((threadIdx.x & 63) < 16) red[wave * 16 + col] = s;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x < 16) {
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w * 16 + col];
+    }
+    return t;                                          // valid in threads 0..15 (column = threadIdx.x)
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* psum, const float* psq, int nblk, int M, int C,
+                                                           float eps, float mom, float* mean, float* rstd, float* rmean,
+                                                           float* rvar) {
+    __shared__ double red[256];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const double s1 = colsum16(psum, nblk, C, c, c < C, red);
+    const double s2 = colsum16(psq, nblk, C, c, c < C, red);
+    if (threadIdx.x < 16 && c < C) {
         const double mu = s1 / M;
         double var = s2 / M - mu * mu;
         if (var < 0.0) var = 0.0;
@@ -137,29 +168,23 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* psum, con
     }
 }
 
-__global__ __launch_bounds__(256) void col_reduce_kernel(const float* part, int nblk, int C, float* out, int accumulate) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int b = lane; b < nblk; b += 64) s += (double)part[(size_t)b * C + c];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (lane == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
+__global__ __launch_bounds__(1024) void col_reduce_kernel(const float* part, int nblk, int C, float* out, int accumulate) {
+    __shared__ double red[256];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const double s = colsum16(part, nblk, C, c, c < C, red);
+    if (threadIdx.x < 16 && c < C) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 // two partial arrays of the same shape in one launch (dbeta / dgamma of a BatchNorm backward)
-__global__ __launch_bounds__(256) void col_reduce2_kernel(const float* part1, const float* part2, int nblk, int C, float* out1, float* out2) {
-    int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (c >= 2 * C) return;
+__global__ __launch_bounds__(1024) void col_reduce2_kernel(const float* part1, const float* part2, int nblk, int C, float* out1, float* out2) {
+    __shared__ double red[256];
+    int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const bool ok = c < 2 * C;
     const float* part = c < C ? part1 : part2;
     float* out = c < C ? out1 : out2;
     if (c >= C) c -= C;
-    double s = 0.0;
-    for (int b = lane; b < nblk; b += 64) s += (double)part[(size_t)b * C + c];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (lane == 0) out[c] = (float)s;
+    const double s = colsum16(part, nblk, C, c, ok, red);
+    if (threadIdx.x < 16 && ok) out[c] = (float)s;
 }
 
 // Streaming kernels: a thread keeps ONE column vector (its BN parameters live in registers) and strides over
@@ -461,7 +486,7 @@ extern "C" int dm_bn_finalize(const float* psum, const float* psq, int nblk, int
                               float* mean, float* rstd, float* running_mean, float* running_var, dm_stream_t s) {
     DM_CHECK_ARG(psum && psq && mean && rstd && nblk > 0 && M > 0 && C > 0, "dm_bn_finalize: bad arguments");
     DM_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "dm_bn_finalize: running_mean/var must come together");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)s, psum, psq, nblk, M, C, eps, momentum,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, (hipStream_t)s, psum, psq, nblk, M, C, eps, momentum,
                        mean, rstd, running_mean, running_var);
     DM_LAUNCH_CHECK();
     return DM_OK;
@@ -469,14 +494,14 @@ extern "C" int dm_bn_finalize(const float* psum, const float* psq, int nblk, int
 
 extern "C" int dm_col_reduce(const float* part, int nblk, int C, float* out, int accumulate, dm_stream_t s) {
     DM_CHECK_ARG(part && out && nblk > 0 && C > 0, "dm_col_reduce: bad arguments");
-    hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)s, part, nblk, C, out, accumulate);
+    hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, (hipStream_t)s, part, nblk, C, out, accumulate);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
 
 extern "C" int dm_col_reduce2(const float* part1, const float* part2, int nblk, int C, float* out1, float* out2, dm_stream_t s) {
     DM_CHECK_ARG(part1 && part2 && out1 && out2 && nblk > 0 && C > 0, "dm_col_reduce2: bad arguments");
-    hipLaunchKernelGGL(col_reduce2_kernel, dim3(cdiv(2 * C, 4)), dim3(256), 0, (hipStream_t)s, part1, part2, nblk, C, out1, out2);
+    hipLaunchKernelGGL(col_reduce2_kernel, dim3(cdiv(2 * C, 16)), dim3(1024), 0, (hipStream_t)s, part1, part2, nblk, C, out1, out2);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

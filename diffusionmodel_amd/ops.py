@@ -138,12 +138,6 @@ def packed_T(w, dtype, taps, np_):
     return _packed_T_core(w, ("T", dtype, tuple(taps), np_), n, t, c, taps, np_, dtype)
 
 
-def packed_T2d(w):
-    """[K][N] fp32 transpose of a dense-layer weight [N][K] (input gradient of the dense layers)."""
-    n, k = w.shape
-    return _packed_T_core(w, ("linT",), n, 1, k, [0], n, torch.float32)
-
-
 def _packed_T_core(w, key, n, t, c, taps, np_, dtype):
     def build():
         reg = _T_PACKS.get((id(w), key))
@@ -580,37 +574,19 @@ class GroupNormAct(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # fp32 dense layers / activations on small matrices
 # ------------------------------------------------------------------------------------------------
-def _mfma_linear(M, K, N):
-    """Route a dense fp32 layer through the exact-fp32 MFMA GEMM kernels when the vector widths allow."""
-    return K % 4 == 0 and N % 4 == 0
-
-
 def _lin_fwd(x, w, b, y):
-    """y[M][N] = x[M][K] w[N][K]^T + b, fp32.  MFMA path: the rows of x are "pixels" of a 1x1 image, w is already [N][K]."""
+    """y[M][N] = x[M][K] w[N][K]^T + b, fp32 (dense.hip: one wave-level MFMA pass per launch; odd widths: the plain sgemm)."""
     M, K = x.shape
-    N = w.shape[0]
-    if _mfma_linear(M, K, N):
-        _conv_call(x, None, ptr(w), K, y, dtype=torch.float32, B=M, Hi=1, Wi=1, C1=K, C2=0, Hq=1, Wq=1, sy=1, sx=1, T=1,
-                   KW=1, ty=1, tx=1, oy0=0, ox0=0, Ho=1, Wo=1, N=N, shift=b)
-    else:
-        call("dm_linear_fwd", ptr(x), ptr(w), ptr(b), ptr(y), M, K, N, ACT_NONE)
+    call("dm_linear_fwd", ptr(x), ptr(w), ptr(b), ptr(y), M, K, w.shape[0], ACT_NONE)
 
 
 def _lin_bwd(x, w, g, dx, dw, db):
     """dx = g w (overwritten), dw += g^T x, db += colsum(g); any of dx/dw/db may be None."""
     M, K = x.shape
     N = w.shape[0]
-    if not _mfma_linear(M, K, N):
-        call("dm_linear_bwd", ptr(x), ptr(w), ptr(g), ptr(dx), ptr(dw), ptr(db), M, K, N)
-        return
-    if dx is not None:
-        wt = packed_T2d(w)                       # refreshed with all other transposed packs after the optimiser step
-        _conv_call(g, None, ptr(wt), N, dx, dtype=torch.float32, B=M, Hi=1, Wi=1, C1=N, C2=0, Hq=1, Wq=1, sy=1, sx=1,
-                   T=1, KW=1, ty=1, tx=1, oy0=0, ox0=0, Ho=1, Wo=1, N=K)
-    if dw is not None or db is not None:
-        tgt = dw if dw is not None else _gzeros((N, K), x)
-        _wgrad_call(g, x, None, tgt, db, dtype=torch.float32, B=M, Hi=1, Wi=1, C1=K, C2=0, Hq=1, Wq=1, sy=1, sx=1, T=1,
-                    KW=1, ty=1, tx=1, oy0=0, ox0=0, Ho=1, Wo=1, N=N, ldy=N, ldw=K)
+    if dw is None and db is not None:
+        dw = _gzeros((N, K), x)
+    call("dm_linear_bwd", ptr(x), ptr(w), ptr(g), ptr(dx), ptr(dw), ptr(db), M, K, N)
 
 
 class Linear(torch.autograd.Function):
@@ -725,6 +701,7 @@ class SeResidual(torch.autograd.Function):
             return out
         R = w1.shape[0]
         y = _empty((B, Cc), torch.float32, x2)
+        L.ensure_workspace()                     # the whole-image pools split their rows over workgroups through it
         call("dm_pool_hw", ptr(x2), dt(x2), B, H * W, Cc, ptr(y))
         hid, gh = _empty((B, R), torch.float32, x2), _empty((B, R), torch.float32, x2)
         logit, sg = _empty((B, Cc), torch.float32, x2), _empty((B, Cc), torch.float32, x2)
@@ -750,6 +727,7 @@ class SeResidual(torch.autograd.Function):
         f = lambda *s: _empty(s, torch.float32, g)
         dsg, dlogit, dgh, dhid, dy = f(B, Cc), f(B, Cc), f(B, R), f(B, R), f(B, Cc)
         dw1, dw2 = _gzeros((R, Cc), g), _gzeros((Cc, R), g)
+        L.ensure_workspace()
         call("dm_scale_residual_bwd_reduce", ptr(g), ptr(x2), dt(dtype), B, H * W, Cc, inv, ptr(dsg))
         call("dm_act_bwd", ptr(logit), ptr(dsg), ptr(dlogit), B * Cc, ACT_SIGMOID)
         _lin_bwd(gh, w2, dlogit, dgh, dw2, None)

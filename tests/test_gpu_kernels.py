@@ -406,6 +406,35 @@ def test_linear_act_and_small_gemm_shapes():
         assert rel_err(bd.grad.cpu(), br.grad) < 5e-5
 
 
+@pytest.mark.parametrize("M,K,N", [(2, 4, 8), (64, 1024, 1024), (64, 1024, 64), (64, 64, 1024), (2048, 128, 8), (2048, 8, 128),
+                                   (200, 20, 36), (1024, 16, 16), (77, 512, 4), (512, 32, 512)])
+def test_dense_layer_kernels_exact_integers(M, K, N):
+    """dense.hip behind dm_linear_fwd / dm_linear_bwd (SE MLP, CoordAttn strip convolutions, EmbedFC): small-integer fp32 data,
+    every product and partial sum exact, so y, dx, dw (accumulated onto a non-zero start, rows split over workgroups with
+    atomics) and db must equal the CPU result bit for bit — ragged M / K / N (K, N multiples of 4) included."""
+    from diffusionmodel_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(M + 3 * K + 7 * N)
+    ri = lambda *s: torch.randint(-2, 3, s, generator=g).float()
+    keep = lambda t, p: t * (torch.rand(t.shape, generator=g) < p).float()       # sparse: |sums| stay far below 2^24
+    x, w, b, gy = keep(ri(M, K), 0.3), keep(ri(N, K), 0.3), ri(N), keep(ri(M, N), 0.3)
+    dw0, db0 = ri(N, K), ri(N)
+    xd, wd, bd, gd = x.to(DEV), w.to(DEV), b.to(DEV), gy.to(DEV)
+    y = torch.full((M, N), 7.0, device=DEV)
+    call("dm_linear_fwd", ptr(xd), ptr(wd), ptr(bd), ptr(y), M, K, N, 0)
+    assert torch.equal(y.cpu(), x @ w.t() + b)
+    y2 = torch.empty((M, N), device=DEV)
+    call("dm_linear_fwd", ptr(xd), ptr(wd), None, ptr(y2), M, K, N, 1)            # no bias, fused GELU (DM_ACT_GELU)
+    assert torch.allclose(y2.cpu(), F.gelu(x @ w.t()), rtol=1e-6, atol=1e-6)
+    dx, dw, db = torch.full((M, K), -3.0, device=DEV), dw0.to(DEV), db0.to(DEV)
+    call("dm_linear_bwd", ptr(xd), ptr(wd), ptr(gd), ptr(dx), ptr(dw), ptr(db), M, K, N)
+    assert torch.equal(dx.cpu(), gy @ w)
+    assert torch.equal(dw.cpu(), dw0 + gy.t() @ x)
+    assert torch.equal(db.cpu(), db0 + gy.sum(0))
+    dx2 = torch.empty((M, K), device=DEV)
+    call("dm_linear_bwd", ptr(xd), ptr(wd), ptr(gd), ptr(dx2), None, None, M, K, N)   # input gradient only
+    assert torch.equal(dx2, dx)
+
+
 def test_loss_qsample_cfg_update_randn():
     o = ops()
     from oracle import unet_ref as O
