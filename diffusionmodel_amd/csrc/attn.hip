@@ -123,6 +123,54 @@ __global__ void scale_res_bwd_kernel(const T* dout, const float* sg, const float
     }
 }
 
+// 16-byte-vector forms (C % VE == 0, aligned): grid.y = sample, a thread walks over the sample's pixels with ONE channel
+// vector, whose gate / mean-gradient values it loads once
+template <typename T>
+__global__ void scale_res_fwd_vec_kernel(const T* x2, const T* res, const float* sg, T* out, int HW, int C, float inv) {
+    constexpr int V = Elem<T>::VE;
+    const int CV = C / V, b = blockIdx.y;
+    const int n = HW * CV;                                  // vectors per sample
+    const int step = (gridDim.x * 256 / CV) * CV;           // a multiple of CV: the channel vector of a thread never changes
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= step) return;
+    const int c = (i % CV) * V;
+    float s[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) s[k] = sg ? sg[b * C + c + k] : 1.f;
+    const size_t base = (size_t)b * n * V;
+    for (; i < n; i += step) {
+        float a[V], r[V];
+        load_vec<T>(x2 + base + (size_t)i * V, a);
+        load_vec<T>(res + base + (size_t)i * V, r);
+#pragma unroll
+        for (int k = 0; k < V; ++k) a[k] = (r[k] + a[k] * s[k]) * inv;
+        store_vec<T>(out + base + (size_t)i * V, a);
+    }
+}
+template <typename T>
+__global__ void scale_res_bwd_vec_kernel(const T* dout, const float* sg, const float* dym, T* dx2, T* dres, int HW, int C, float inv) {
+    constexpr int V = Elem<T>::VE;
+    const int CV = C / V, b = blockIdx.y;
+    const int n = HW * CV;
+    const int step = (gridDim.x * 256 / CV) * CV;
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= step) return;
+    const int c = (i % CV) * V;
+    const float ihw = 1.f / (float)HW;
+    float s[V], m[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { s[k] = sg ? sg[b * C + c + k] : 1.f; m[k] = dym ? dym[b * C + c + k] * ihw : 0.f; }
+    const size_t base = (size_t)b * n * V;
+    for (; i < n; i += step) {
+        float g[V], d[V];
+        load_vec<T>(dout + base + (size_t)i * V, g);
+#pragma unroll
+        for (int k = 0; k < V; ++k) { g[k] *= inv; d[k] = g[k] * s[k] + m[k]; }
+        store_vec<T>(dx2 + base + (size_t)i * V, d);
+        store_vec<T>(dres + base + (size_t)i * V, g);
+    }
+}
+
 // ---- coordinate attention gate ------------------------------------------------------------------
 __device__ inline void ca_mix(const float* alpha, const float* beta, float& al, float& be) {
     const float sa = sigmoid_f(alpha[0]), sb = sigmoid_f(beta[0]);
@@ -320,10 +368,25 @@ extern "C" int dm_pool_hw(const void* x, int dtype, int B, int HW, int C, float*
     return launch_strip<0>(x, nullptr, mean_bc, dtype, B, 1, HW, 0, 1, HW, C, 1.f / (float)HW, ST);
 }
 
+// workgroups per sample for the vector kernels above: ~4 vectors per thread, at least one whole pixel row of vectors per pass
+static int sr_grid(int HW, int CV, int B) {
+    int64_t g = ((int64_t)HW * CV + 256 * 4 - 1) / (256 * 4);
+    const int64_t need = (CV + 255) / 256;
+    if (g < need) g = need;
+    const int64_t cap = 8192 / (B > 0 ? B : 1) + 1;
+    if (g > cap) g = cap;
+    return (int)(g < need ? need : g);
+}
+
 extern "C" int dm_scale_residual_fwd(const void* x2, const void* res, const float* sgate, void* out, int dtype, int B, int HW, int C,
                                      float inv, dm_stream_t s) {
     DM_CHECK_ARG(x2 && res && out && B > 0 && HW > 0 && C > 0, "dm_scale_residual_fwd: bad arguments");
-    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((scale_res_fwd_kernel<T>), dim3(grid_for((int64_t)B * HW * C, 256)), dim3(256), 0, ST, (const T*)x2, (const T*)res, sgate, (T*)out, B, HW, C, inv));
+    DM_DISPATCH_DTYPE(dtype, {
+        if (C % Elem<T>::VE == 0 && (((uintptr_t)x2 | (uintptr_t)res | (uintptr_t)out) & 15) == 0)
+            hipLaunchKernelGGL((scale_res_fwd_vec_kernel<T>), dim3(sr_grid(HW, C / Elem<T>::VE, B), B), dim3(256), 0, ST, (const T*)x2, (const T*)res, sgate, (T*)out, HW, C, inv);
+        else
+            hipLaunchKernelGGL((scale_res_fwd_kernel<T>), dim3(grid_for((int64_t)B * HW * C, 256)), dim3(256), 0, ST, (const T*)x2, (const T*)res, sgate, (T*)out, B, HW, C, inv);
+    });
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
@@ -337,7 +400,12 @@ extern "C" int dm_scale_residual_bwd_reduce(const void* dout, const void* x2, in
 extern "C" int dm_scale_residual_bwd_apply(const void* dout, const float* sgate, const float* dy_mean, void* dx2, void* dres, int dtype,
                                            int B, int HW, int C, float inv, dm_stream_t s) {
     DM_CHECK_ARG(dout && dx2 && dres && B > 0 && HW > 0 && C > 0, "dm_scale_residual_bwd_apply: bad arguments");
-    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((scale_res_bwd_kernel<T>), dim3(grid_for((int64_t)B * HW * C, 256)), dim3(256), 0, ST, (const T*)dout, sgate, dy_mean, (T*)dx2, (T*)dres, B, HW, C, inv));
+    DM_DISPATCH_DTYPE(dtype, {
+        if (C % Elem<T>::VE == 0 && (((uintptr_t)dout | (uintptr_t)dx2 | (uintptr_t)dres) & 15) == 0)
+            hipLaunchKernelGGL((scale_res_bwd_vec_kernel<T>), dim3(sr_grid(HW, C / Elem<T>::VE, B), B), dim3(256), 0, ST, (const T*)dout, sgate, dy_mean, (T*)dx2, (T*)dres, HW, C, inv);
+        else
+            hipLaunchKernelGGL((scale_res_bwd_kernel<T>), dim3(grid_for((int64_t)B * HW * C, 256)), dim3(256), 0, ST, (const T*)dout, sgate, dy_mean, (T*)dx2, (T*)dres, B, HW, C, inv);
+    });
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

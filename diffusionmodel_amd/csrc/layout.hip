@@ -230,6 +230,68 @@ __global__ void upcat_bwd_kernel(const T* dy, T* dx1, T* dx2, int B, int H, int 
     }
 }
 
+// The same gather for H, W >= 4 with the taps in registers: the outputs whose interpolation touches input row i lie in an
+// 8-wide window starting at floor((i - 1) / scale) - 1 (2 / scale <= 4.7 there), so each axis is 8 statically indexed
+// (weight, index) pairs — the AxisTaps form above indexes its arrays dynamically, which puts them in scratch memory and ran
+// the 32x32 -> 64x64 gradient at 180 us for 170 MB of traffic.
+template <int NT>
+__device__ __forceinline__ void window_taps(int i, float scale, int in, int out, int (&idx)[NT], float (&w)[NT]) {
+    int lo = (int)floorf((float)(i - 1) / scale) - 1;
+    lo = lo < 0 ? 0 : lo;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int o = lo + j;
+        float ww = 0.f;
+        if (o < out) {
+            int i0, i1; float l0, l1;
+            bil_coef(o, scale, in, i0, i1, l0, l1);
+            if (i0 == i) ww += l0;
+            if (i1 == i) ww += l1;
+        }
+        idx[j] = o < out ? o : out - 1;
+        w[j] = ww;
+    }
+}
+
+template <typename T, int V>
+__global__ void upcat_bwd_win_kernel(const T* dy, T* dx1, T* dx2, int B, int H, int W, int C1, int C2) {
+    const int C = C1 + C2, CV = C / V, Ho = 2 * H, Wo = 2 * W;
+    const float sy = (float)(H - 1) / (float)(Ho - 1), sx = (float)(W - 1) / (float)(Wo - 1);
+    const int64_t total = (int64_t)B * H * W * CV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        int64_t r = i / CV;
+        const int ix = (int)(r % W); r /= W;
+        const int iy = (int)(r % H);
+        const int b = (int)(r / H);
+        int oy[8], ox[8];
+        float wy[8], wx[8];
+        window_taps<8>(iy, sy, H, Ho, oy, wy);
+        window_taps<8>(ix, sx, W, Wo, ox, wx);
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+        const int c = cv * V;
+        const T* base = dy + (size_t)b * Ho * Wo * C + c;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            if (wy[a] == 0.f) continue;
+            const T* row = base + (size_t)oy[a] * Wo * C;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (wx[q] == 0.f) continue;
+                float g[V];
+                ldv<T, V>(row + (size_t)ox[q] * C, g);
+                const float w = wy[a] * wx[q];
+#pragma unroll
+                for (int k = 0; k < V; ++k) acc[k] += w * g[k];
+            }
+        }
+        if (c < C1) stv<T, V>(dx1 + (((size_t)b * H + iy) * W + ix) * C1 + c, acc);
+        else stv<T, V>(dx2 + (((size_t)b * H + iy) * W + ix) * C2 + (c - C1), acc);
+    }
+}
+
 template <typename T, int V>
 __global__ void cat_kernel(const T* x1, const T* x2, T* y, int64_t M, int C1, int C2, int bwd) {
     // fwd: y[m] = [x1[m] | x2[m]];  bwd: x1[m], x2[m] <- y[m]  (x pointers are then outputs)
@@ -426,7 +488,8 @@ extern "C" int dm_upcat_bwd(const void* dy, void* dx1, void* dx2, int dtype, int
     DM_CHECK_ARG(dy && dx1 && (C2 == 0 || dx2) && B > 0 && H > 0 && W > 0 && C1 > 0 && C2 >= 0, "dm_upcat_bwd: bad arguments");
     const int C = C1 + C2;
     DM_DISPATCH_DTYPE(dtype, {
-        if (al16<T>(C1, C2, dy, dx1, dx2)) hipLaunchKernelGGL((upcat_bwd_kernel<T, Elem<T>::VE>), dim3(grid_for((int64_t)B * H * W * C / Elem<T>::VE, 256)), dim3(256), 0, ST, (const T*)dy, (T*)dx1, (T*)dx2, B, H, W, C1, C2);
+        if (al16<T>(C1, C2, dy, dx1, dx2) && H >= 4 && W >= 4) hipLaunchKernelGGL((upcat_bwd_win_kernel<T, Elem<T>::VE>), dim3(grid_for((int64_t)B * H * W * C / Elem<T>::VE, 256, 1 << 16)), dim3(256), 0, ST, (const T*)dy, (T*)dx1, (T*)dx2, B, H, W, C1, C2);
+        else if (al16<T>(C1, C2, dy, dx1, dx2)) hipLaunchKernelGGL((upcat_bwd_kernel<T, Elem<T>::VE>), dim3(grid_for((int64_t)B * H * W * C / Elem<T>::VE, 256)), dim3(256), 0, ST, (const T*)dy, (T*)dx1, (T*)dx2, B, H, W, C1, C2);
         else hipLaunchKernelGGL((upcat_bwd_kernel<T, 1>), dim3(grid_for((int64_t)B * H * W * C, 256)), dim3(256), 0, ST, (const T*)dy, (T*)dx1, (T*)dx2, B, H, W, C1, C2);
     });
     DM_LAUNCH_CHECK();
