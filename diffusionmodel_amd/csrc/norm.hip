@@ -447,6 +447,146 @@ __global__ __launch_bounds__(256) void gn_bwd_vec_kernel(const T* x, const T* dy
     }
 }
 
+// ---- GroupNorm on large images: pixel slabs instead of one workgroup per (sample, group) ----------------------------------------
+// The kernels above give a workgroup the cg channels of ONE group: 32 bytes out of every 256-byte pixel row at C = 128, G = 8 —
+// strided 32-byte reads, 512 workgroups, two serial passes: 1.1 TB/s on the 64x64 `out` head (180 us backward).  Here a workgroup
+// takes a slab of whole pixel rows of one sample (fully coalesced), a thread keeps one channel vector:
+//   stats kernel : per-slab partial sums of every group -> scratch[b][slab][g][2]      (backward: also dgamma / dbeta)
+//   apply kernel : every workgroup adds up its sample's slab partials in a fixed order (deterministic), then streams.
+template <typename T, int V, bool BWD>
+__global__ __launch_bounds__(256) void gn_slab_stats_kernel(const T* x, const T* dy, int HW, int C, int G, int pps, const float* gamma,
+                                                            const float* beta, int act, const float* mean_i, const float* rstd_i,
+                                                            float* part, float* part_db, float* part_dg) {
+    extern __shared__ float sm[];                        // backward: [256][2 V] per-thread channel sums
+    const int b = blockIdx.y, slab = blockIdx.x, S = gridDim.x;
+    const int CVt = C / V, cg = C / G;
+    const int v0 = threadIdx.x % CVt, p0 = threadIdx.x / CVt, pstep = 256 / CVt;
+    const int c0 = v0 * V, g = c0 / cg;
+    float gm[V], bt[V], a1[V], a2[V];
+    float mu = 0.f, rs = 1.f;
+    if constexpr (BWD) {
+        mu = mean_i[b * G + g];
+        rs = rstd_i[b * G + g];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { gm[k] = gamma[c0 + k]; bt[k] = beta[c0 + k]; a1[k] = 0.f; a2[k] = 0.f; }
+    }
+    const size_t base = (size_t)b * HW * C + c0;
+    const int lo = slab * pps, hi = min(HW, lo + pps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+    for (int pix = lo + p0; pix < hi; pix += pstep) {
+        float xv[V];
+        load_vec<T>(x + base + (size_t)pix * C, xv);
+        if constexpr (!BWD) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) { s1 += xv[k]; s2 += xv[k] * xv[k]; }
+        } else {
+            float gv[V];
+            load_vec<T>(dy + base + (size_t)pix * C, gv);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float xh = (xv[k] - mu) * rs;
+                const float gg = gv[k] * act_grad_t<T>(xh * gm[k] + bt[k], act);
+                s1 += gg * gm[k];
+                s2 += gg * gm[k] * xh;
+                a1[k] += gg;
+                a2[k] += gg * xh;
+            }
+        }
+    }
+    // group sums in a fixed order (the forward result must not depend on the run: graph replay == eager, bit for bit)
+    __shared__ float thr[512];
+    thr[2 * threadIdx.x] = s1;
+    thr[2 * threadIdx.x + 1] = s2;
+    if constexpr (BWD) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) { sm[threadIdx.x * 2 * V + k] = a1[k]; sm[threadIdx.x * 2 * V + V + k] = a2[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * G) {
+        const int gg = threadIdx.x >> 1, which = threadIdx.x & 1, vpg = cg / V;      // vectors per group and pixel
+        float t = 0.f;
+        for (int p = 0; p < pstep; ++p)
+            for (int v = 0; v < vpg; ++v) t += thr[2 * (p * CVt + gg * vpg + v) + which];
+        part[((size_t)b * S + slab) * 2 * G + threadIdx.x] = t;
+    }
+    if constexpr (BWD) {                                 // per-channel sums of this slab -> one row of the dbeta / dgamma partial arrays
+        for (int i = threadIdx.x; i < 2 * C; i += 256) {
+            const int which = i / C, c = i - which * C, v = c / V, k = c - v * V;
+            float t = 0.f;
+            for (int p = 0; p < pstep; ++p) t += sm[(p * CVt + v) * 2 * V + which * V + k];
+            (which ? part_dg : part_db)[((size_t)b * S + slab) * C + c] = t;
+        }
+    }
+}
+
+template <typename T, int V, bool BWD>
+__global__ __launch_bounds__(256) void gn_slab_apply_kernel(const T* x, const T* dy, T* out, int HW, int C, int G, int pps, int S, float eps,
+                                                            const float* gamma, const float* beta, int act, const float* part,
+                                                            float* mean_io, float* rstd_io) {
+    const int b = blockIdx.y, slab = blockIdx.x;
+    const int CVt = C / V, cg = C / G;
+    const int v0 = threadIdx.x % CVt, p0 = threadIdx.x / CVt, pstep = 256 / CVt;
+    const int c0 = v0 * V, g = c0 / cg;
+    float t1 = 0.f, t2 = 0.f;
+    for (int k = 0; k < S; ++k) {                         // the same order in every workgroup of the sample
+        t1 += part[((size_t)b * S + k) * 2 * G + 2 * g];
+        t2 += part[((size_t)b * S + k) * 2 * G + 2 * g + 1];
+    }
+    const float n = (float)HW * cg;
+    float gm[V], bt[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { gm[k] = gamma[c0 + k]; bt[k] = beta[c0 + k]; }
+    float mu, rs, m1 = 0.f, m2 = 0.f;
+    if constexpr (!BWD) {
+        mu = t1 / n;
+        float var = t2 / n - mu * mu;
+        var = var < 0.f ? 0.f : var;
+        rs = rsqrtf(var + eps);
+        if (slab == 0 && p0 == 0 && c0 == g * cg) { mean_io[b * G + g] = mu; rstd_io[b * G + g] = rs; }
+    } else {
+        mu = mean_io[b * G + g];
+        rs = rstd_io[b * G + g];
+        m1 = t1 / n;
+        m2 = t2 / n;
+    }
+    const size_t base = (size_t)b * HW * C + c0;
+    const int lo = slab * pps, hi = min(HW, lo + pps);
+#pragma unroll 4
+    for (int pix = lo + p0; pix < hi; pix += pstep) {
+        float xv[V];
+        load_vec<T>(x + base + (size_t)pix * C, xv);
+        if constexpr (!BWD) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) xv[k] = act_apply_t<T>((xv[k] - mu) * rs * gm[k] + bt[k], act);
+        } else {
+            float gv[V];
+            load_vec<T>(dy + base + (size_t)pix * C, gv);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float xh = (xv[k] - mu) * rs;
+                const float gg = gv[k] * act_grad_t<T>(xh * gm[k] + bt[k], act);
+                xv[k] = rs * (gg * gm[k] - m1 - xh * m2);
+            }
+        }
+        store_vec<T>(out + base + (size_t)pix * C, xv);
+    }
+}
+
+// slab geometry for a (B, HW) problem: ~2048 workgroups, >= 64 pixels per slab; 0 = use the per-group kernels
+static int gn_slabs(int B, int HW, int C, int G, int V, const void* a, const void* b2, const void* c2, int* pps) {
+    const int cg = C / G;
+    if (C % V != 0 || cg % V != 0 || 256 % (C / V) != 0 || C / V > 256 || HW < 1024 || dm_g_ws == nullptr) return 0;
+    if ((((uintptr_t)a | (uintptr_t)b2 | (uintptr_t)c2) & 15) != 0) return 0;
+    int S = 2048 / B;
+    if (S > HW / 64) S = HW / 64;
+    if (S < 2) return 0;
+    *pps = cdiv(HW, S);
+    S = cdiv(HW, *pps);
+    if ((int64_t)B * S * (2 * G + 2 * C + 64) * (int64_t)sizeof(float) > dm_g_ws_bytes) return 0;
+    return S;
+}
+
 // grid of the per-thread-column streaming kernels: >= 8 vectors per thread (the 4 x V channel parameters a
 // thread keeps in registers are then amortised), at most 8 workgroups per CU, at least one pass over a row
 int stream_grid(int64_t nvec, int cv) {
@@ -568,7 +708,12 @@ extern "C" int dm_gn_act_fwd(const void* x, void* y, int dtype, int B, int HW, i
     DM_DISPATCH_DTYPE(dtype, {
         constexpr int V = Elem<T>::VE;
         const int cg = C / G;
-        if (cg % V == 0 && 256 % (cg / V) == 0 && C % V == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
+        int pps = 0;
+        const int S = gn_slabs(B, HW, C, G, V, x, y, nullptr, &pps);
+        if (S > 0) {
+            hipLaunchKernelGGL((gn_slab_stats_kernel<T, V, false>), dim3(S, B), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)nullptr, HW, C, G, pps, gamma, beta, act, (const float*)nullptr, (const float*)nullptr, dm_g_ws, (float*)nullptr, (float*)nullptr);
+            hipLaunchKernelGGL((gn_slab_apply_kernel<T, V, false>), dim3(S, B), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)nullptr, (T*)y, HW, C, G, pps, S, eps, gamma, beta, act, (const float*)dm_g_ws, mean, rstd);
+        } else if (cg % V == 0 && 256 % (cg / V) == 0 && C % V == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
             hipLaunchKernelGGL((gn_fwd_vec_kernel<T, V>), dim3(B * G), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, HW, C, G, eps, gamma, beta, act, mean, rstd);
         else
             hipLaunchKernelGGL((gn_fwd_kernel<T>), dim3(B * G), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, HW, C, G, eps, gamma, beta, act, mean, rstd);
@@ -585,7 +730,16 @@ extern "C" int dm_gn_act_bwd(const void* x, const void* dy, void* dx, int dtype,
     DM_DISPATCH_DTYPE(dtype, {
         constexpr int V = Elem<T>::VE;
         const int cg = C / G;
-        if (cg % V == 0 && 256 % (cg / V) == 0 && C % V == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0)
+        int pps = 0;
+        const int S = gn_slabs(B, HW, C, G, V, x, dy, dx, &pps);
+        if (S > 0) {
+            float* pdb = dm_g_ws + (((size_t)B * S * 2 * G + 63) & ~(size_t)63);
+            float* pdg = pdb + (size_t)B * S * C;
+            hipLaunchKernelGGL((gn_slab_stats_kernel<T, V, true>), dim3(S, B), dim3(256), 256 * 2 * V * sizeof(float), (hipStream_t)s, (const T*)x, (const T*)dy, HW, C, G, pps, gamma, beta, act, mean, rstd, dm_g_ws, pdb, pdg);
+            hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, (hipStream_t)s, (const float*)pdb, B * S, C, dbeta, 1);
+            hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, (hipStream_t)s, (const float*)pdg, B * S, C, dgamma, 1);
+            hipLaunchKernelGGL((gn_slab_apply_kernel<T, V, true>), dim3(S, B), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, HW, C, G, pps, S, 0.f, gamma, beta, act, (const float*)dm_g_ws, (float*)mean, (float*)rstd);
+        } else if (cg % V == 0 && 256 % (cg / V) == 0 && C % V == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0)
             hipLaunchKernelGGL((gn_bwd_vec_kernel<T, V>), dim3(B * G), dim3(256), shm, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, HW, C, G, gamma, beta, act, mean, rstd, dgamma, dbeta);
         else
             hipLaunchKernelGGL((gn_bwd_kernel<T>), dim3(B * G), dim3(256), shm, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, HW, C, G, gamma, beta, act, mean, rstd, dgamma, dbeta);

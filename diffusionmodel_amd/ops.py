@@ -553,6 +553,7 @@ class GroupNormAct(torch.autograd.Function):
         B, H, W, Cc = x.shape
         y = _empty(x.shape, x.dtype, x)
         mean, rstd = _empty((B * groups,), torch.float32, x), _empty((B * groups,), torch.float32, x)
+        L.ensure_workspace()                     # large images: per-slab partial sums
         call("dm_gn_act_fwd", ptr(x), ptr(y), dt(x), B, H * W, Cc, groups, BN_EPS, ptr(gamma), ptr(beta), act, ptr(mean), ptr(rstd))
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         ctx.meta = (groups, act)
@@ -566,6 +567,7 @@ class GroupNormAct(torch.autograd.Function):
         g = g.contiguous()
         dx = _empty(x.shape, x.dtype, x)
         dgamma, dbeta = _gzeros((Cc,), x), _gzeros((Cc,), x)
+        L.ensure_workspace()
         call("dm_gn_act_bwd", ptr(x), ptr(g), ptr(dx), dt(x), B, H * W, Cc, groups, ptr(gamma), ptr(beta), act, ptr(mean), ptr(rstd),
              ptr(dgamma), ptr(dbeta))
         return dx, dgamma, dbeta, None, None

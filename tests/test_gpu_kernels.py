@@ -304,9 +304,10 @@ def test_conv_transpose(k, h, dtype):
 
 @pytest.mark.parametrize("act_name", ["relu", "gelu"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_groupnorm_act(act_name, dtype):
+@pytest.mark.parametrize("B,Cc,H", [(3, 32, 6), (3, 64, 40), (2, 128, 64)], ids=["per-group", "slabs-ragged", "slabs-64x64"])
+def test_groupnorm_act(act_name, dtype, B, Cc, H):
+    """(3, 32, 6): one workgroup per (sample, group); the larger images take the pixel-slab kernels (ragged last slab at 40x40)."""
     o = ops()
-    B, Cc, H = 3, 32, 6
     gn = torch.nn.GroupNorm(8, Cc)
     with torch.no_grad():
         gn.weight.uniform_(0.5, 1.5); gn.bias.uniform_(-0.3, 0.3)
