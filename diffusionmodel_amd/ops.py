@@ -282,10 +282,14 @@ def _bn_eval_fold(spec, bias):
 
 def _running_stats(bn, n):
     """(mean, rstd) of an eval-mode BatchNorm from its running statistics (dm_bn_fold with gamma=1, beta=0)."""
-    ones, zeros = torch.ones_like(bn.running_var), torch.zeros_like(bn.running_var)
-    rstd, dummy = torch.empty_like(bn.running_var), torch.empty_like(bn.running_var)
-    call("dm_bn_fold", ptr(ones), ptr(zeros), ptr(zeros), ptr(bn.running_var), None, BN_EPS, n, ptr(rstd), ptr(dummy))
-    return bn.running_mean.clone(), rstd
+    key = ("rstats", bn.running_mean._version, bn.running_var._version, getattr(bn, "_stat_epoch", 0))
+
+    def build():                                  # once per set of statistics: the sampler calls this every step
+        ones, zeros = torch.ones_like(bn.running_var), torch.zeros_like(bn.running_var)
+        rstd, dummy = torch.empty_like(bn.running_var), torch.empty_like(bn.running_var)
+        call("dm_bn_fold", ptr(ones), ptr(zeros), ptr(zeros), ptr(bn.running_var), None, BN_EPS, n, ptr(rstd), ptr(dummy))
+        return bn.running_mean.clone(), rstd
+    return _cached(key, bn.running_var, build)
 
 
 class ConvBnAct(torch.autograd.Function):
