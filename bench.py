@@ -257,7 +257,7 @@ def main():
 
     if rank == 0:
         value = world * args.steps / elapsed
-        out = {"metric": "denoiser-steps/sec (train fwd+bwd+clip+AdamW, 64x64, B=64/GPU)", "value": round(value, 4),
+        out = {"metric": f"denoiser-steps/sec (train fwd+bwd+clip+AdamW, {args.size}x{args.size}, B={args.batch}/GPU)", "value": round(value, 4),
                "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
