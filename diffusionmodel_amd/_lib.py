@@ -22,7 +22,7 @@ vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 class DmConv(C.Structure):
     _fields_ = [(n, vp) for n in ("in1", "in2", "w", "scale", "shift", "out", "psum", "psq")] + [
         (n, i32) for n in ("dtype", "act", "out_nchw_f32", "B", "Hi", "Wi", "C1", "C2", "Hq", "Wq", "sy", "sx", "T", "KW",
-                           "ty", "tx", "oy0", "ox0", "Ho", "Wo", "osy", "osx", "ooy", "oox", "N", "ldw", "ldc", "coff")]
+                           "ty", "tx", "oy0", "ox0", "Ho", "Wo", "osy", "osx", "ooy", "oox", "N", "ldw", "ldc", "coff", "in2_batch")]
 
 
 class DmWgrad(C.Structure):
@@ -69,6 +69,7 @@ _PROTOS = {
     "dm_film_fwd": [vp, vp, vp, vp, i32, i32, i32, i32],
     "dm_film_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32],
     "dm_upcat_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32],
+    "dm_upcat_fwd_bcast": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32],
     "dm_upcat_bwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32],
     "dm_cat_fwd": [vp, vp, vp, i32, i32, i32, i32],
     "dm_cat_bwd": [vp, vp, vp, i32, i32, i32, i32],
@@ -94,7 +95,7 @@ _PROTOS = {
     "dm_randn_dev": [vp, i64, u64, vp],
     "dm_pack_multi": [vp, vp, vp, i32],
 }
-_NO_STREAM = {"dm_last_conv_path": ([], i32), "dm_set_workspace": ([vp, i64], i32), "dm_set_conv_variant": ([i32], i32), "dm_set_wgrad_variant": ([i32], i32), "dm_version": ([], i32), "dm_last_error": ([], C.c_char_p), "dm_colstat_blocks": ([i32], i32)}
+_NO_STREAM = {"dm_last_conv_path": ([], i32), "dm_get_conv_variant": ([], i32), "dm_set_workspace": ([vp, i64], i32), "dm_set_conv_variant": ([i32], i32), "dm_set_wgrad_variant": ([i32], i32), "dm_version": ([], i32), "dm_last_error": ([], C.c_char_p), "dm_colstat_blocks": ([i32], i32)}
 
 EXPORTED = sorted(list(_PROTOS) + list(_NO_STREAM))
 

@@ -55,6 +55,7 @@ struct ConvP {
     // channel chunks (halo kernel) and leaves its accumulators in ws; splitk_epilogue_kernel adds them up and finishes
     int splits, kper;
     float* ws;
+    int B2;                                      // batch of the second source (in2 is read at sample b % B2); == B unless broadcast
 };
 
 // raw accumulators of one 128 x BN tile as they sit in the registers: [tile][wave][nt][mt][lane] float4 (1 KiB per store)
@@ -556,8 +557,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
         const int y = y0 + hy - 1, x = TW == 8 ? hx - img * 10 - 1 : x0 + hx - 1;
         const bool ok = (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi && img < 4 && hx < TW + 2 + (TW == 8 ? 30 : 0);
         const int pix = ((b + img) * p.Hi + y) * p.Wi + x;
+        const int pix2 = (((b + img) % p.B2) * p.Hi + y) * p.Wi + x;          // CFG sampler: the skip tensor of n samples feeds 2n
         hv1[i] = ok && slotb < p.C1 * 2 ? (unsigned)(pix * p.C1 * 2 + slotb) : OOB;
-        hv2[i] = ok ? (unsigned)(pix * p.C2 * 2 + slotb) : OOB;
+        hv2[i] = ok ? (unsigned)(pix2 * p.C2 * 2 + slotb) : OOB;
     }
     unsigned wv[2];                                        // weight pieces 2 wave + j: 8 rows (n) x 128 B
 #pragma unroll
@@ -602,7 +604,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
         const int c0 = chunk << 6;
         const bool first = c0 < p.C1;
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? p.in1 : p.in2), 0,
-                                                                           pix_img * (first ? p.C1 : p.C2) * 2, SRD_FLAGS);
+                                                                           first ? pix_img * p.C1 * 2 : p.B2 * p.Hi * p.Wi * p.C2 * 2, SRD_FLAGS);
         const unsigned v = first ? hv1[i] : hv2[i];
         const int q = min(wave + 8 * i, NP - 1);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_dst)(smem + buf * HALO_BYTES + q * 1024), 16, live ? v : OOB,
@@ -809,6 +811,7 @@ extern "C" int dm_set_conv_variant(int variant) {
 }
 
 extern "C" int dm_last_conv_path(void) { return g_last_path; }
+extern "C" int dm_get_conv_variant(void) { return g_variant; }
 
 extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
     DM_CHECK_ARG(d != nullptr, "dm_conv: null descriptor");
@@ -835,6 +838,12 @@ extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
     p.Ho = d->Ho; p.Wo = d->Wo; p.osy = d->osy; p.osx = d->osx; p.ooy = d->ooy; p.oox = d->oox;
     p.N = d->N; p.ldw = d->ldw; p.ldc = d->ldc; p.coff = d->coff; p.M = (int)M;
     p.splits = 1; p.kper = 1 << 24; p.ws = nullptr;
+    p.B2 = d->in2_batch > 0 ? d->in2_batch : d->B;
+    if (p.B2 != p.B) {                           // broadcast second source: the halo-resident kernel only
+        DM_CHECK_ARG(d->C2 > 0 && d->B % p.B2 == 0, "dm_conv: in2_batch=%d must divide B=%d", p.B2, d->B);
+        DM_CHECK_ARG(d->dtype == DM_BF16 && g_variant >= 5 && halo_eligible(p),
+                     "dm_conv: a broadcast second source (in2_batch) needs the halo-resident 3x3 kernel (bf16, stride 1, 16/32/64-pixel rows)");
+    }
     // the LDS-DMA kernel indexes with unsigned 32-bit element offsets (with a margin for the halo arithmetic)
     const int64_t in_elems = (int64_t)d->B * d->Hi * d->Wi * (d->C1 > d->C2 ? d->C1 : d->C2);
     const int64_t w_elems = (int64_t)d->N * d->ldw;

@@ -149,7 +149,7 @@ __device__ inline void bil_coef(int o, float scale, int in, int& i0, int& i1, fl
 }
 
 template <typename T, int V>
-__global__ void upcat_fwd_kernel(const T* x1, const T* x2, T* y, int B, int H, int W, int C1, int C2) {
+__global__ void upcat_fwd_kernel(const T* x1, const T* x2, T* y, int B, int H, int W, int C1, int C2, int B2) {
     const int C = C1 + C2, CV = C / V, Ho = 2 * H, Wo = 2 * W;
     const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
     const int64_t total = (int64_t)B * Ho * Wo * CV;
@@ -164,8 +164,9 @@ __global__ void upcat_fwd_kernel(const T* x1, const T* x2, T* y, int B, int H, i
         bil_coef(ox, sx, W, x0, x1i, w0, w1);
         const int c = cv * V;
         const T* src; int Cs, cc;
-        if (c < C1) { src = x1; Cs = C1; cc = c; } else { src = x2; Cs = C2; cc = c - C1; }
-        const T* sb = src + (size_t)b * H * W * Cs + cc;
+        int bs = b;
+        if (c < C1) { src = x1; Cs = C1; cc = c; } else { src = x2; Cs = C2; cc = c - C1; bs = b % B2; }   // x2 may hold B2 < B samples (CFG)
+        const T* sb = src + (size_t)bs * H * W * Cs + cc;
         float a[V], bq[V], cq[V], d[V], o[V];
         ldv<T, V>(sb + ((size_t)y0 * W + x0) * Cs, a);
         ldv<T, V>(sb + ((size_t)y0 * W + x1i) * Cs, bq);
@@ -473,15 +474,19 @@ extern "C" int dm_film_bwd(const void* x, const void* dy, const float* cemb, voi
     return DM_OK;
 }
 
-extern "C" int dm_upcat_fwd(const void* x1, const void* x2, void* y, int dtype, int B, int H, int W, int C1, int C2, dm_stream_t s) {
+extern "C" int dm_upcat_fwd_bcast(const void* x1, const void* x2, void* y, int dtype, int B, int B2, int H, int W, int C1, int C2, dm_stream_t s) {
     DM_CHECK_ARG(x1 && y && (C2 == 0 || x2) && B > 0 && H > 0 && W > 0 && C1 > 0 && C2 >= 0, "dm_upcat_fwd: bad arguments");
+    DM_CHECK_ARG(B2 > 0 && B % B2 == 0, "dm_upcat_fwd_bcast: the batch of x2 (%d) must divide B (%d)", B2, B);
     const int C = C1 + C2;
     DM_DISPATCH_DTYPE(dtype, {
-        if (al16<T>(C1, C2, x1, x2, y)) hipLaunchKernelGGL((upcat_fwd_kernel<T, Elem<T>::VE>), dim3(grid_for((int64_t)B * 4 * H * W * C / Elem<T>::VE, 256)), dim3(256), 0, ST, (const T*)x1, (const T*)x2, (T*)y, B, H, W, C1, C2);
-        else hipLaunchKernelGGL((upcat_fwd_kernel<T, 1>), dim3(grid_for((int64_t)B * 4 * H * W * C, 256)), dim3(256), 0, ST, (const T*)x1, (const T*)x2, (T*)y, B, H, W, C1, C2);
+        if (al16<T>(C1, C2, x1, x2, y)) hipLaunchKernelGGL((upcat_fwd_kernel<T, Elem<T>::VE>), dim3(grid_for((int64_t)B * 4 * H * W * C / Elem<T>::VE, 256)), dim3(256), 0, ST, (const T*)x1, (const T*)x2, (T*)y, B, H, W, C1, C2, B2);
+        else hipLaunchKernelGGL((upcat_fwd_kernel<T, 1>), dim3(grid_for((int64_t)B * 4 * H * W * C, 256)), dim3(256), 0, ST, (const T*)x1, (const T*)x2, (T*)y, B, H, W, C1, C2, B2);
     });
     DM_LAUNCH_CHECK();
     return DM_OK;
+}
+extern "C" int dm_upcat_fwd(const void* x1, const void* x2, void* y, int dtype, int B, int H, int W, int C1, int C2, dm_stream_t s) {
+    return dm_upcat_fwd_bcast(x1, x2, y, dtype, B, B, H, W, C1, C2, s);
 }
 
 extern "C" int dm_upcat_bwd(const void* dy, void* dx1, void* dx2, int dtype, int B, int H, int W, int C1, int C2, dm_stream_t s) {

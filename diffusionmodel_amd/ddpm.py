@@ -108,7 +108,12 @@ class DDPM(_HipBlock):
         temb1, temb2 = net.time_emb1(t2.reshape(-1, 1)), net.time_emb2(t2.reshape(-1, 1))
         embs = (ctx_embs[0], temb1, ctx_embs[1], temb2)
         if dedup and not net.training:
-            feats = tuple(repeat2(f) for f in net.encode(x_i))       # encoder + up0 once on n (exact in eval mode)
+            # encoder + up0 once on n (exact in eval mode); the skip tensors stay at batch n — the decoder's upsample-concat and the
+            # head convolution read sample b % n (no doubled copies: x0 alone is 67 MB) — only the small bottleneck map is doubled
+            x0, d1, d2, d3, d4, u1 = net.encode(x_i)
+            F, (n, H, W) = x0.shape[3], x0.shape[:3]
+            bc = ops.conv_bcast_ok(x0.dtype, 2 * n, H, W, F, F)      # the head conv's broadcast second source needs the halo-resident kernel
+            feats = (x0 if bc else repeat2(x0), d1, d2, d3, d4, repeat2(u1))
         else:
             feats = net.encode(repeat2(x_i))
         return net.decode(feats, embs)

@@ -210,9 +210,10 @@ def refresh_packs():
 # ------------------------------------------------------------------------------------------------
 def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0,
                Ho, Wo, N, osy=1, osx=1, ooy=0, oox=0, ldc=None, coff=0, scale=None, shift=None, act=ACT_NONE,
-               psum=None, psq=None, out_nchw=False):
+               psum=None, psq=None, out_nchw=False, in2_batch=0):
     L.ensure_workspace()          # split-K partial tiles of small, deep problems
     d = L.DmConv()
+    d.in2_batch = in2_batch
     d.in1, d.in2, d.w = ptr(in1), ptr(in2), w_ptr
     d.scale, d.shift, d.out, d.psum, d.psq = ptr(scale), ptr(shift), ptr(out), ptr(psum), ptr(psq)
     d.dtype, d.act, d.out_nchw_f32 = dt(dtype), act, int(out_nchw)
@@ -292,6 +293,18 @@ def _running_stats(bn, n):
     return _cached(key, bn.running_var, build)
 
 
+def conv_bcast_ok(dtype, B, H, W, C1, C2):
+    """Can a 3x3 stride-1 conv read its second source with a smaller batch (DmConv.in2_batch)?  Mirrors halo_eligible() in
+    igemm.hip: bf16, whole 64-channel chunks, rows of 16 / 32 / 64 pixels (or multiples of 64), four 8x8 images per tile."""
+    if dtype != torch.bfloat16 or C1 % 64 or C2 % 64 or L.load().dm_get_conv_variant() < 5:
+        return False
+    if W == 8:
+        return H == 8 and B % 4 == 0
+    if W > 64:
+        return W % 64 == 0 and H % 4 == 0
+    return W in (16, 32, 64) and (H * W) % 256 == 0
+
+
 class ConvBnAct(torch.autograd.Function):
     """y = act(BN(conv(cat(x, x2)) + b)) as ONE autograd node.
 
@@ -313,6 +326,9 @@ class ConvBnAct(torch.autograd.Function):
         C2 = x2.shape[3] if x2 is not None else 0
         N, Cin = w.shape[0], w.shape[1]
         dtype = x.dtype
+        bcast = x2 is not None and x2.shape[0] != B           # CFG sampler: skip tensor of n samples under a batch of 2n
+        if bcast and (need_grad or B % x2.shape[0] or spec.bn is not None and spec.bn.training):
+            raise L.DmError(f"conv: second source with batch {x2.shape[0]} under batch {B} is inference-only (and must divide it)")
         s, p = spec.stride, spec.pad
         Ho = (Hi + 2 * p - spec.kh) // s + 1
         Wo = (Wi + 2 * p - spec.kw) // s + 1
@@ -326,6 +342,8 @@ class ConvBnAct(torch.autograd.Function):
         M = B * Ho * Wo
         geom = dict(dtype=dtype, B=B, Hi=Hi, Wi=Wi, C1=C1, C2=C2, Hq=Ho, Wq=Wo, sy=s, sx=s, T=T, KW=spec.kw, ty=1, tx=1,
                     oy0=-p, ox0=-p, Ho=Ho, Wo=Wo, N=N)
+        if bcast:
+            geom["in2_batch"] = x2.shape[0]
         bn = spec.bn
         ctx.spec, ctx.geom, ctx.has_bn, ctx.C2, ctx.Cin = spec, geom, bn is not None, C2, Cin
         ctx.bias_present = b is not None
@@ -825,7 +843,12 @@ class UpCat(torch.autograd.Function):
         B, H, W, C1 = x1.shape
         C2 = x2.shape[3]
         y = _empty((B, 2 * H, 2 * W, C1 + C2), x1.dtype, x1)
-        call("dm_upcat_fwd", ptr(x1), ptr(x2), ptr(y), dt(x1), B, H, W, C1, C2)
+        if x2.shape[0] != B:                     # CFG sampler: the skip tensor was computed once for both halves of the batch
+            if any(ctx.needs_input_grad):
+                raise L.DmError("UpCat: a skip tensor with a smaller batch is inference-only")
+            call("dm_upcat_fwd_bcast", ptr(x1), ptr(x2), ptr(y), dt(x1), B, x2.shape[0], H, W, C1, C2)
+        else:
+            call("dm_upcat_fwd", ptr(x1), ptr(x2), ptr(y), dt(x1), B, H, W, C1, C2)
         ctx.meta = (B, H, W, C1, C2, x1.dtype)
         return y
 

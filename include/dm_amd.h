@@ -55,6 +55,9 @@ typedef struct DmConv {
     int32_t T, KW, ty, tx, oy0, ox0;
     int32_t Ho, Wo, osy, osx, ooy, oox;
     int32_t N, ldw, ldc, coff;
+    int32_t in2_batch;                            /* 0 or B: in2 has B samples.  n < B (n | B): in2 has n samples and sample b reads
+                                                     b % n — the CFG sampler's doubled batch over a skip tensor computed once
+                                                     (halo-resident 3x3 kernel only) */
 } DmConv;
 int dm_conv(const DmConv* d, dm_stream_t stream);
 /* tuning knob: staging pipeline of dm_conv — 1 = register staging, 2..4 = LDS-DMA gather ring with that many stages,
@@ -62,6 +65,8 @@ int dm_conv(const DmConv* d, dm_stream_t stream);
 int dm_set_conv_variant(int variant);
 /* which kernel family the last dm_conv call launched: 0 = gather kernel (conv_igemm*), 1 = conv3x3_halo_kernel (profiling aid) */
 int dm_last_conv_path(void);
+/* the value dm_set_conv_variant last set (default 5) */
+int dm_get_conv_variant(void);
 
 /* Weight gradient of the same gather convolution (fp32 atomics into dw, which the caller zeroes or
  * accumulates into):  dw[n*ldw + t*C + c] += sum_m dy[orow(m)][n] * in(pix(m,t))[c],
@@ -189,6 +194,9 @@ int dm_film_bwd(const void* x, const void* dy, const float* cemb, void* dx, floa
                 int HW, int C, dm_stream_t s);
 /* concat(x1,x2) along C then bilinear x2 upsample, align_corners=True (new_scripy.py:242,251) */
 int dm_upcat_fwd(const void* x1, const void* x2, void* y, int dtype, int B, int H, int W, int C1, int C2, dm_stream_t s);
+/* the same with x2 holding B2 samples (B2 | B): sample b reads x2[b % B2] — the CFG sampler's doubled batch over skip tensors
+ * that the encoder computed once; forward only */
+int dm_upcat_fwd_bcast(const void* x1, const void* x2, void* y, int dtype, int B, int B2, int H, int W, int C1, int C2, dm_stream_t s);
 int dm_upcat_bwd(const void* dy, void* dx1, void* dx2, int dtype, int B, int H, int W, int C1, int C2, dm_stream_t s);
 /* plain channel concat / split (MNIST UnetUp, MNIST_script.py:95) */
 int dm_cat_fwd(const void* x1, const void* x2, void* y, int dtype, int M, int C1, int C2, dm_stream_t s);

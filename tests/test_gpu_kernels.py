@@ -436,6 +436,31 @@ def test_dense_layer_kernels_exact_integers(M, K, N):
     assert torch.equal(dx2, dx)
 
 
+def test_broadcast_second_source_equals_repeated_batch():
+    """CFG sampler: skip tensors of n samples under a batch of 2n (DmConv.in2_batch, dm_upcat_fwd_bcast) — bit-identical to
+    feeding the repeated tensor, and refused where it cannot work (autograd, a gather-kernel shape)."""
+    o = ops()
+    n, F, S = 4, 64, 32
+    g = torch.Generator().manual_seed(9)
+    x1 = torch.randn(2 * n, S, S, F, generator=g).to(DEV).bfloat16()
+    x2 = torch.randn(n, S, S, F, generator=g).to(DEV).bfloat16()
+    with torch.no_grad():
+        a = o.UpCat.apply(x1, x2)
+        b = o.UpCat.apply(x1, torch.cat([x2, x2]))
+        assert torch.equal(a, b)
+        conv = Holder((torch.randn(F, 2 * F, 3, 3, generator=g) * 0.05).to(DEV), torch.randn(F, generator=g).to(DEV))
+        spec = o.ConvSpec(3, 3, 1, 1)
+        ya = o.conv_bn_act(x1, x2, conv, None, spec)
+        yb = o.conv_bn_act(x1, torch.cat([x2, x2]), conv, None, spec)
+        assert torch.equal(ya, yb)
+        assert o.conv_bcast_ok(torch.bfloat16, 2 * n, S, S, F, F) and not o.conv_bcast_ok(torch.float32, 2 * n, S, S, F, F)
+        with pytest.raises(Exception):                       # 32 channels: not a halo-kernel shape -> the library refuses
+            o.conv_bn_act(x1[..., :32].contiguous(), x2[..., :32].contiguous(),
+                          Holder(torch.randn(F, 64, 3, 3).to(DEV), torch.randn(F).to(DEV)), None, spec)
+    with pytest.raises(Exception):                           # training graph: inference-only
+        o.UpCat.apply(x1.clone().requires_grad_(True), x2)
+
+
 def test_loss_qsample_cfg_update_randn():
     o = ops()
     from oracle import unet_ref as O
