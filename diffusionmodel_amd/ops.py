@@ -12,6 +12,7 @@ Conventions
   and autograd bookkeeping only.
 """
 import ctypes as C
+import threading
 
 import weakref
 
@@ -208,20 +209,38 @@ def refresh_packs():
 # ------------------------------------------------------------------------------------------------
 # dm_conv / dm_conv_wgrad descriptors
 # ------------------------------------------------------------------------------------------------
+_DESC_TLS = threading.local()
+
+
+def _desc_cache():
+    c = getattr(_DESC_TLS, "cache", None)
+    if c is None:
+        c = _DESC_TLS.cache = {}
+    return c
+
+
 def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0,
                Ho, Wo, N, osy=1, osx=1, ooy=0, oox=0, ldc=None, coff=0, scale=None, shift=None, act=ACT_NONE,
                psum=None, psq=None, out_nchw=False, in2_batch=0):
     L.ensure_workspace()          # split-K partial tiles of small, deep problems
-    d = L.DmConv()
-    d.in2_batch = in2_batch
+    # the geometry half of the descriptor is the same every step: one ctypes struct per distinct call, only the eight pointers
+    # change (filling 37 fields costs ~6 us of Python per launch; the backward pass runs on autograd's thread, hence per thread)
+    key = (dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0, Ho, Wo, N, osy, osx, ooy, oox, ldc, coff, act,
+           out_nchw, in2_batch, ldw)
+    cache = _desc_cache()
+    d = cache.get(key)
+    if d is None:
+        d = L.DmConv()
+        d.dtype, d.act, d.out_nchw_f32 = dt(dtype), act, int(out_nchw)
+        d.B, d.Hi, d.Wi, d.C1, d.C2 = B, Hi, Wi, C1, C2
+        d.Hq, d.Wq, d.sy, d.sx = Hq, Wq, sy, sx
+        d.T, d.KW, d.ty, d.tx, d.oy0, d.ox0 = T, KW, ty, tx, oy0, ox0
+        d.Ho, d.Wo, d.osy, d.osx, d.ooy, d.oox = Ho, Wo, osy, osx, ooy, oox
+        d.N, d.ldw, d.ldc, d.coff = N, ldw, (N if ldc is None else ldc), coff
+        d.in2_batch = in2_batch
+        cache[key] = d
     d.in1, d.in2, d.w = ptr(in1), ptr(in2), w_ptr
     d.scale, d.shift, d.out, d.psum, d.psq = ptr(scale), ptr(shift), ptr(out), ptr(psum), ptr(psq)
-    d.dtype, d.act, d.out_nchw_f32 = dt(dtype), act, int(out_nchw)
-    d.B, d.Hi, d.Wi, d.C1, d.C2 = B, Hi, Wi, C1, C2
-    d.Hq, d.Wq, d.sy, d.sx = Hq, Wq, sy, sx
-    d.T, d.KW, d.ty, d.tx, d.oy0, d.ox0 = T, KW, ty, tx, oy0, ox0
-    d.Ho, d.Wo, d.osy, d.osx, d.ooy, d.oox = Ho, Wo, osy, osx, ooy, oox
-    d.N, d.ldw, d.ldc, d.coff = N, ldw, (N if ldc is None else ldc), coff
     kind = "conv_igemm" if dtype == torch.bfloat16 else "igemm_f32"
     if PROFILE is None or kind not in PROFILE_KINDS:
         call("dm_conv", C.byref(d))
@@ -239,14 +258,19 @@ def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, s
 def _wgrad_call(dy, in1, in2, dw, dbias, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0, Ho, Wo, N, ldy,
                 ldw, osy=1, osx=1, ooy=0, oox=0, splitk=0):
     L.ensure_workspace()          # split partial sums of the halo-resident weight-gradient kernel
-    d = L.DmWgrad()
+    key = ("w", dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0, Ho, Wo, N, ldy, ldw, osy, osx, ooy, oox, splitk)
+    cache = _desc_cache()
+    d = cache.get(key)
+    if d is None:
+        d = L.DmWgrad()
+        d.dtype = dt(dtype)
+        d.B, d.Hi, d.Wi, d.C1, d.C2 = B, Hi, Wi, C1, C2
+        d.Hq, d.Wq, d.sy, d.sx = Hq, Wq, sy, sx
+        d.T, d.KW, d.ty, d.tx, d.oy0, d.ox0 = T, KW, ty, tx, oy0, ox0
+        d.Ho, d.Wo, d.osy, d.osx, d.ooy, d.oox = Ho, Wo, osy, osx, ooy, oox
+        d.N, d.ldy, d.ldw, d.splitk = N, ldy, ldw, splitk
+        cache[key] = d
     d.dy, d.in1, d.in2, d.dw, d.dbias = ptr(dy), ptr(in1), ptr(in2), ptr(dw), ptr(dbias)
-    d.dtype = dt(dtype)
-    d.B, d.Hi, d.Wi, d.C1, d.C2 = B, Hi, Wi, C1, C2
-    d.Hq, d.Wq, d.sy, d.sx = Hq, Wq, sy, sx
-    d.T, d.KW, d.ty, d.tx, d.oy0, d.ox0 = T, KW, ty, tx, oy0, ox0
-    d.Ho, d.Wo, d.osy, d.osx, d.ooy, d.oox = Ho, Wo, osy, osx, ooy, oox
-    d.N, d.ldy, d.ldw, d.splitk = N, ldy, ldw, splitk
     kind = "conv_wgrad" if dtype == torch.bfloat16 else "wgrad_f32"
     if PROFILE is None or kind not in PROFILE_KINDS:
         call("dm_conv_wgrad", C.byref(d))
