@@ -170,8 +170,10 @@ int dm_sigmix_fwd(const float* x, const float* y, const float* gamma, float* xo,
 int dm_sigmix_bwd(const float* dxo, const float* y, const float* gamma, float* dy, float* dgamma, int n, dm_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
- * Small dense layers in fp32 (EmbedFC new_scripy.py:255-268; CoordAttn 1x1 convs on strips :76-91).
- *   y[M][N] = act(x[M][K] w[N][K]^T + b)
+ * Small dense layers in fp32 (EmbedFC new_scripy.py:255-268; CoordAttn 1x1 convs on strips :76-91; SE MLP :148-157).
+ *   y[M][N] = act(x[M][K] w[N][K]^T + b);   backward: dx = dy w (overwritten), dw += dy^T x, db += column sums of dy
+ *   (any of dx / dw / db may be NULL).  K % 4 == 0, N % 4 == 0 and 16-byte aligned tensors take the MFMA kernels of dense.hip
+ *   (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation; dw / db by fp32 atomics), anything else a plain SGEMM.
  * ---------------------------------------------------------------------------------------------- */
 int dm_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act, dm_stream_t s);
 int dm_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int M, int K, int N,
