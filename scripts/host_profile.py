@@ -30,6 +30,9 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
+torch.autograd.set_multithreading_enabled(False)      # backward on this thread, so that cProfile sees the Python backward functions
+step()
+torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(5):
@@ -37,4 +40,4 @@ for _ in range(5):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(22)
+st.sort_stats("tottime").print_stats(40)
