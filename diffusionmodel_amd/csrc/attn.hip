@@ -214,6 +214,55 @@ __global__ void ca_gate_bwd_dx_kernel(const T* dout, const float* lh, const floa
     }
 }
 
+// 16-byte-vector form of the three per-pixel CoordAttn kernels (C % VE == 0, aligned): grid.y = sample, a thread keeps one channel
+// vector and walks over the pixels (32-bit index math; the scalar forms above divide 64-bit indices per element: 18 us for 33 MB).
+//   GATE: out = in * (al sigmoid(lh[b,y,c]) + be sigmoid(lw[b,x,c]))        (forward, and dx of the gate with in = dout)
+//   POOL: out = in + sh[b,y,c] / W + sw[b,x,c] / H                          (backward of the strip means; in may be NULL)
+template <typename T, bool GATE>
+__global__ void ca_pix_vec_kernel(const T* in, const float* sh, const float* sw, const float* alpha, const float* beta, T* out, int H, int W,
+                                  int C) {
+    constexpr int V = Elem<T>::VE;
+    const int CV = C / V, b = blockIdx.y, n = H * W * CV;
+    const int step = (gridDim.x * 256 / CV) * CV;
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= step) return;
+    const int c = (i % CV) * V;
+    float al = 0.f, be = 0.f;
+    if constexpr (GATE) ca_mix(alpha, beta, al, be);
+    else { al = 1.f / (float)W; be = 1.f / (float)H; }
+    const size_t base = (size_t)b * n * V;
+    for (; i < n; i += step) {
+        const int pix = i / CV, yy = pix / W, xx = pix - yy * W;
+        const float* ph = sh + ((size_t)b * H + yy) * C + c;
+        const float* pw = sw + ((size_t)b * W + xx) * C + c;
+        float v[V];
+        if (in) load_vec<T>(in + base + (size_t)i * V, v);
+        else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) v[k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            if constexpr (GATE) v[k] *= al * sigmoid_f(ph[k]) + be * sigmoid_f(pw[k]);
+            else v[k] = v[k] + ph[k] * al + pw[k] * be;
+        }
+        store_vec<T>(out + base + (size_t)i * V, v);
+    }
+}
+template <typename T, bool GATE>
+static bool launch_ca_pix(const T* in, const float* sh, const float* sw, const float* alpha, const float* beta, T* out, int B, int H, int W, int C,
+                          hipStream_t st) {
+    constexpr int V = Elem<T>::VE;
+    if (C % V != 0 || C / V > 256 || ((((uintptr_t)in | (uintptr_t)out)) & 15) != 0 || (int64_t)H * W * (C / V) >= (1ll << 31)) return false;
+    const int CV = C / V;
+    int64_t g = ((int64_t)H * W * CV + 256 * 4 - 1) / (256 * 4);
+    const int64_t need = (CV + 255) / 256, cap = 8192 / B + 1;
+    if (g > cap) g = cap;
+    if (g < need) g = need;
+    hipLaunchKernelGGL((ca_pix_vec_kernel<T, GATE>), dim3((unsigned)g, B), dim3(256), 0, st, in, sh, sw, alpha, beta, out, H, W, C);
+    return true;
+}
+
 // strip sums S[b,a,c] = sum_r dout*x  ->  dl = mix * sig'(l) * S ;  dmix += sum sig(l) * S
 __global__ void ca_gate_bwd_strip_kernel(const float* S, const float* l, const float* alpha, const float* beta, int which,
                                          float* dl, float* dmix, int64_t n) {
@@ -420,7 +469,10 @@ extern "C" int dm_ca_pool_fwd(const void* x, int dtype, int B, int H, int W, int
 extern "C" int dm_ca_pool_bwd(const float* dxh, const float* dxw, const void* dout_gate, void* dx, int dtype, int B, int H, int W, int C,
                               dm_stream_t s) {
     DM_CHECK_ARG(dxh && dxw && dx && B > 0 && H > 0 && W > 0 && C > 0, "dm_ca_pool_bwd: bad arguments");
-    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ca_pool_bwd_kernel<T>), dim3(grid_for((int64_t)B * H * W * C, 256)), dim3(256), 0, ST, dxh, dxw, (const T*)dout_gate, (T*)dx, B, H, W, C));
+    DM_DISPATCH_DTYPE(dtype, {
+        if (!launch_ca_pix<T, false>((const T*)dout_gate, dxh, dxw, nullptr, nullptr, (T*)dx, B, H, W, C, ST))
+            hipLaunchKernelGGL((ca_pool_bwd_kernel<T>), dim3(grid_for((int64_t)B * H * W * C, 256)), dim3(256), 0, ST, dxh, dxw, (const T*)dout_gate, (T*)dx, B, H, W, C);
+    });
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
@@ -428,7 +480,10 @@ extern "C" int dm_ca_pool_bwd(const float* dxh, const float* dxw, const void* do
 extern "C" int dm_ca_gate_fwd(const void* x, const float* lh, const float* lw, const float* alpha, const float* beta, void* out, int dtype,
                               int B, int H, int W, int C, dm_stream_t s) {
     DM_CHECK_ARG(x && lh && lw && alpha && beta && out && B > 0 && H > 0 && W > 0 && C > 0, "dm_ca_gate_fwd: bad arguments");
-    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ca_gate_fwd_kernel<T>), dim3(grid_for((int64_t)B * H * W * C, 256)), dim3(256), 0, ST, (const T*)x, lh, lw, alpha, beta, (T*)out, B, H, W, C));
+    DM_DISPATCH_DTYPE(dtype, {
+        if (!launch_ca_pix<T, true>((const T*)x, lh, lw, alpha, beta, (T*)out, B, H, W, C, ST))
+            hipLaunchKernelGGL((ca_gate_fwd_kernel<T>), dim3(grid_for((int64_t)B * H * W * C, 256)), dim3(256), 0, ST, (const T*)x, lh, lw, alpha, beta, (T*)out, B, H, W, C);
+    });
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
@@ -439,7 +494,10 @@ extern "C" int dm_ca_gate_bwd(const void* x, const void* dout, const float* lh, 
                               dm_stream_t s) {
     DM_CHECK_ARG(x && dout && lh && lw && alpha && beta && dx_gate && dlh && dlw && dalpha_dbeta && B > 0 && H > 0 && W > 0 && C > 0,
                  "dm_ca_gate_bwd: bad arguments");
-    DM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ca_gate_bwd_dx_kernel<T>), dim3(grid_for((int64_t)B * H * W * C, 256)), dim3(256), 0, ST, (const T*)dout, lh, lw, alpha, beta, (T*)dx_gate, B, H, W, C));
+    DM_DISPATCH_DTYPE(dtype, {
+        if (!launch_ca_pix<T, true>((const T*)dout, lh, lw, alpha, beta, (T*)dx_gate, B, H, W, C, ST))
+            hipLaunchKernelGGL((ca_gate_bwd_dx_kernel<T>), dim3(grid_for((int64_t)B * H * W * C, 256)), dim3(256), 0, ST, (const T*)dout, lh, lw, alpha, beta, (T*)dx_gate, B, H, W, C);
+    });
     DM_LAUNCH_CHECK();
     hipError_t e = hipMemsetAsync(dalpha_dbeta + 2, 0, 2 * sizeof(float), ST);
     if (e != hipSuccess) { dm_set_error("dm_ca_gate_bwd: memset failed"); return (int)e; }
