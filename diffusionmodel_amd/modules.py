@@ -276,6 +276,9 @@ class EmbedFC(_HipBlock):
 
     def forward(self, x):
         x = x.reshape(-1, self.input_dim).float()
+        if not torch.is_grad_enabled():          # sampler: GELU in the epilogue of the first dense layer
+            h = ops.linear_act(x, self.model[0].weight, self.model[0].bias, ACT_GELU)
+            return ops.linear_act(h, self.model[2].weight, self.model[2].bias, ACT_NONE)
         h = ops.Linear.apply(x, self.model[0].weight, self.model[0].bias)
         h = ops.Act.apply(h, ACT_GELU)
         return ops.Linear.apply(h, self.model[2].weight, self.model[2].bias)

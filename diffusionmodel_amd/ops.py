@@ -622,10 +622,10 @@ class GroupNormAct(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # fp32 dense layers / activations on small matrices
 # ------------------------------------------------------------------------------------------------
-def _lin_fwd(x, w, b, y):
-    """y[M][N] = x[M][K] w[N][K]^T + b, fp32 (dense.hip: one wave-level MFMA pass per launch; odd widths: the plain sgemm)."""
+def _lin_fwd(x, w, b, y, act=ACT_NONE):
+    """y[M][N] = act(x[M][K] w[N][K]^T + b), fp32 (dense.hip: one wave-level MFMA pass per launch; odd widths: the plain sgemm)."""
     M, K = x.shape
-    call("dm_linear_fwd", ptr(x), ptr(w), ptr(b), ptr(y), M, K, w.shape[0], ACT_NONE)
+    call("dm_linear_fwd", ptr(x), ptr(w), ptr(b), ptr(y), M, K, w.shape[0], act)
 
 
 def _lin_bwd(x, w, g, dx, dw, db):
@@ -659,6 +659,15 @@ class Linear(torch.autograd.Function):
         db = _gzeros((N,), x) if (ctx.has_b and ctx.needs_input_grad[2]) else None
         _lin_bwd(x, w, g, dx, dw, db)
         return dx, dw, db
+
+
+def linear_act(x, w, b, act):
+    """Inference-only dense layer with the activation in its epilogue (no autograd node)."""
+    L.require_device(x, w)
+    x, w = x.contiguous(), w.contiguous()
+    y = _empty((x.shape[0], w.shape[0]), torch.float32, x)
+    _lin_fwd(x, w, b, y, act)
+    return y
 
 
 def linear(x, w, b=None):
@@ -753,10 +762,14 @@ class SeResidual(torch.autograd.Function):
         call("dm_pool_hw", ptr(x2), dt(x2), B, H * W, Cc, ptr(y))
         hid, gh = _empty((B, R), torch.float32, x2), _empty((B, R), torch.float32, x2)
         logit, sg = _empty((B, Cc), torch.float32, x2), _empty((B, Cc), torch.float32, x2)
-        _lin_fwd(y, w1, None, hid)
-        call("dm_act_fwd", ptr(hid), ptr(gh), B * R, ACT_GELU)
-        _lin_fwd(gh, w2, None, logit)
-        call("dm_act_fwd", ptr(logit), ptr(sg), B * Cc, ACT_SIGMOID)
+        if not any(ctx.needs_input_grad):        # inference (the sampler): activations in the dense epilogues, nothing kept
+            _lin_fwd(y, w1, None, gh, ACT_GELU)
+            _lin_fwd(gh, w2, None, sg, ACT_SIGMOID)
+        else:
+            _lin_fwd(y, w1, None, hid)
+            call("dm_act_fwd", ptr(hid), ptr(gh), B * R, ACT_GELU)
+            _lin_fwd(gh, w2, None, logit)
+            call("dm_act_fwd", ptr(logit), ptr(sg), B * Cc, ACT_SIGMOID)
         call("dm_scale_residual_fwd", ptr(x2), ptr(res), ptr(sg), ptr(out), dt(x2), B, H * W, Cc, inv)
         ctx.save_for_backward(x2, y, hid, gh, logit, sg, w1, w2)
         ctx.meta = (R, inv, x2.shape, x2.dtype)
