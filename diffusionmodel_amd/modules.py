@@ -114,8 +114,15 @@ class CoordAttn(_HipBlock):
         if H != W:
             raise DmError("CoordAttn on the HIP path needs H == W (the reference's adaptive pools are then the identity)")
         xh, xw = ops.PoolStrips.apply(x)                                           # :102-103
-        xh = ops.BnActMatrix.apply(_strip_conv(xh, self.conv1_h), self.bn1_h.weight, self.bn1_h.bias, self.bn1_h, self._sp_h, ACT_GELU)
-        xw = ops.BnActMatrix.apply(_strip_conv(xw, self.conv1_w), self.bn1_w.weight, self.bn1_w.bias, self.bn1_w, self._sp_w, ACT_GELU)
+        if not torch.is_grad_enabled() and not self.bn1_h.training and not self.bn1_w.training:
+            # sampler: running-statistics BatchNorm folded into the dense weights, GELU in the epilogue (:105-111 in one launch each)
+            wh, bh = ops.folded_dense_bn(self.conv1_h, self._sp_h)
+            ww, bw = ops.folded_dense_bn(self.conv1_w, self._sp_w)
+            xh = ops.linear_act(xh.reshape(-1, C), wh, bh, ACT_GELU).reshape(B, H, -1)
+            xw = ops.linear_act(xw.reshape(-1, C), ww, bw, ACT_GELU).reshape(B, W, -1)
+        else:
+            xh = ops.BnActMatrix.apply(_strip_conv(xh, self.conv1_h), self.bn1_h.weight, self.bn1_h.bias, self.bn1_h, self._sp_h, ACT_GELU)
+            xw = ops.BnActMatrix.apply(_strip_conv(xw, self.conv1_w), self.bn1_w.weight, self.bn1_w.bias, self.bn1_w, self._sp_w, ACT_GELU)
         h2w = _strip_conv(xh, self.h2w_proj)                                       # :113
         w2h = _strip_conv(xw, self.w2h_proj)                                       # :114
         xh = ops.SigMix.apply(xh, w2h, self.gamma_h)                               # :125

@@ -305,6 +305,19 @@ def _bn_eval_fold(spec, bias):
     return _cached(key, bn.weight, build)
 
 
+def folded_dense_bn(conv, spec):
+    """Eval-mode BatchNorm folded INTO a 1x1-conv / dense layer's weights: (W', b') with BN(W x + b) = W' x + b' — inference only,
+    rebuilt when the weights or the statistics change (CoordAttn's conv1_* + bn1_* on strips: one launch instead of two)."""
+    sc, sh = _bn_eval_fold(spec, conv.bias)
+    w = conv.weight
+    key = ("dense_fold", w._version, sc.data_ptr())
+
+    def build():
+        with torch.no_grad():
+            return (w.reshape(w.shape[0], -1).float() * sc[:, None]).contiguous()
+    return _cached(key, w, build), sh
+
+
 def _running_stats(bn, n):
     """(mean, rstd) of an eval-mode BatchNorm from its running statistics (dm_bn_fold with gamma=1, beta=0)."""
     key = ("rstats", bn.running_mean._version, bn.running_var._version, getattr(bn, "_stat_epoch", 0))
