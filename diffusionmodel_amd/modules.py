@@ -150,7 +150,7 @@ class SEBlock(_HipBlock):
 
     def _fwd(self, x):
         zero = torch.zeros_like(x)
-        return ops.SeResidual.apply(x, zero, self.fc[0].weight, self.fc[2].weight, 1.0)
+        return ops.SeResidual.apply(x, zero, self.fc[0].weight, self.fc[2].weight, 1.0, torch.is_grad_enabled())
 
     def forward(self, x):
         return self._nchw_call(x)
@@ -206,7 +206,7 @@ class ResConvBlock(_HipBlock):
             return x2
         res = x if self.same_ch else x1
         if self._with_se:
-            return ops.SeResidual.apply(x2, res, self.se.fc[0].weight, self.se.fc[2].weight, INV_1414)
+            return ops.SeResidual.apply(x2, res, self.se.fc[0].weight, self.se.fc[2].weight, INV_1414, torch.is_grad_enabled())
         return ops.SeResidual.apply(x2, res, None, None, INV_1414)
 
     def forward(self, x):

@@ -759,7 +759,7 @@ class BnActMatrix(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 class SeResidual(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x2, res, w1, w2, inv):
+    def forward(ctx, x2, res, w1, w2, inv, need_grad=True):
         L.require_device(x2, res)
         x2, res = x2.contiguous(), res.contiguous()
         B, H, W, Cc = x2.shape
@@ -775,7 +775,7 @@ class SeResidual(torch.autograd.Function):
         call("dm_pool_hw", ptr(x2), dt(x2), B, H * W, Cc, ptr(y))
         hid, gh = _empty((B, R), torch.float32, x2), _empty((B, R), torch.float32, x2)
         logit, sg = _empty((B, Cc), torch.float32, x2), _empty((B, Cc), torch.float32, x2)
-        if not any(ctx.needs_input_grad):        # inference (the sampler): activations in the dense epilogues, nothing kept
+        if not need_grad:                        # inference (the sampler): activations in the dense epilogues, nothing kept
             _lin_fwd(y, w1, None, gh, ACT_GELU)
             _lin_fwd(gh, w2, None, sg, ACT_SIGMOID)
         else:
@@ -796,7 +796,7 @@ class SeResidual(torch.autograd.Function):
         dx2, dres = _empty(shape, dtype, g), _empty(shape, dtype, g)
         if R is None:
             call("dm_scale_residual_bwd_apply", ptr(g), None, None, ptr(dx2), ptr(dres), dt(dtype), B, H * W, Cc, inv)
-            return dx2, dres, None, None, None
+            return dx2, dres, None, None, None, None
         x2, y, hid, gh, logit, sg, w1, w2 = ctx.saved_tensors
         f = lambda *s: _empty(s, torch.float32, g)
         dsg, dlogit, dgh, dhid, dy = f(B, Cc), f(B, Cc), f(B, R), f(B, R), f(B, Cc)
@@ -808,7 +808,7 @@ class SeResidual(torch.autograd.Function):
         call("dm_act_bwd", ptr(hid), ptr(dgh), ptr(dhid), B * R, ACT_GELU)
         _lin_bwd(y, w1, dhid, dy, dw1, None)
         call("dm_scale_residual_bwd_apply", ptr(g), ptr(sg), ptr(dy), ptr(dx2), ptr(dres), dt(dtype), B, H * W, Cc, inv)
-        return dx2, dres, dw1, dw2, None
+        return dx2, dres, dw1, dw2, None, None
 
 
 # ------------------------------------------------------------------------------------------------
