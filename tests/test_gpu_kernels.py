@@ -436,6 +436,27 @@ def test_dense_layer_kernels_exact_integers(M, K, N):
     assert torch.equal(dx2, dx)
 
 
+@pytest.mark.parametrize("N,coff,ldc", [(128, 128, 256), (64, 8, 136), (128, 4, 132)])
+def test_conv_output_into_channel_slice(N, coff, ldc):
+    """DmConv.ldc / coff (write the N output channels at column `coff` of rows `ldc` wide): the 16-byte-store epilogue (coff and
+    ldc multiples of 8) and the 8-byte one (coff = 4) must both leave the other columns alone and equal the dense output."""
+    o = ops()
+    from diffusionmodel_amd import ops as O
+    B, S, Ci = 2, 16, 64
+    g = torch.Generator().manual_seed(N + coff)
+    x = torch.randn(B, S, S, Ci, generator=g).to(DEV).bfloat16()
+    conv = Holder((torch.randn(N, Ci, 3, 3, generator=g) * 0.05), torch.randn(N, generator=g))
+    spec = o.ConvSpec(3, 3, 1, 1)
+    with torch.no_grad():
+        ref = o.conv_bn_act(x, None, conv, None, spec)                       # (B, S, S, N)
+        wp = O.packed_fwd(conv.weight, torch.bfloat16, Ci)
+        wide = torch.full((B, S, S, ldc), 7.0, device=DEV, dtype=torch.bfloat16)
+        O._conv_call(x, None, O.ptr(wp), 9 * Ci, wide, dtype=torch.bfloat16, B=B, Hi=S, Wi=S, C1=Ci, C2=0, Hq=S, Wq=S, sy=1, sx=1, T=9, KW=3,
+                     ty=1, tx=1, oy0=-1, ox0=-1, Ho=S, Wo=S, N=N, ldc=ldc, coff=coff, shift=conv.bias)
+    assert torch.equal(wide[..., coff:coff + N], ref)
+    assert torch.all(wide[..., :coff] == 7.0) and torch.all(wide[..., coff + N:] == 7.0)
+
+
 def test_broadcast_second_source_equals_repeated_batch():
     """CFG sampler: skip tensors of n samples under a batch of 2n (DmConv.in2_batch, dm_upcat_fwd_bcast) — bit-identical to
     feeding the repeated tensor, and refused where it cannot work (autograd, a gather-kernel shape)."""
