@@ -91,6 +91,10 @@ def cpu_baseline(args):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON: libraries that print banners there (RCCL: "Librccl path : ...") go to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -236,19 +240,30 @@ def main():
                 "mfma_time_share_of_step": round((allconv[1] + fl["conv_wgrad"][1]) / prof_steps / (elapsed / args.steps), 4),
                 "events": "HIP events on the launch stream around every MFMA launch of the last timed step"}
 
-    # ---- CFG sampling rate (rank 0 only, not part of `value`)
+    # ---- CFG sampling rate (not part of `value`): every rank samples its shard of n = batch x world images (no exchange inside the
+    # trajectory); steady-state step rate = difference of two runs, so the one-off graph capture of sample() cancels out
     sample = None
-    if rank == 0 and args.sample_steps > 0:
+    if args.sample_steps > 0:
         ddpm.eval()
         n = args.batch
-        ddpm.sample(n, (3, args.size, args.size), dev, guide_w=2.0, steps=2, seed=1)           # warm-up / caches
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        ddpm.sample(n, (3, args.size, args.size), dev, guide_w=2.0, steps=args.sample_steps, seed=1, use_graph=True)
-        torch.cuda.synchronize()
-        ts_ = time.perf_counter() - t1
-        sample = {"steps_per_s": round(args.sample_steps / ts_, 3), "n": n, "denoiser_batch": 2 * n, "guide_w": 2.0,
-                  "hipgraph": True, "encoder_dedup": True, "steps_timed": args.sample_steps}
+
+        def run(k):
+            torch.cuda.synchronize()
+            if use_dp:
+                torch.distributed.barrier()
+            t1 = time.perf_counter()
+            parallel.sample_sharded(ddpm, n * world, (3, args.size, args.size), dev, guide_w=2.0, steps=k, seed=1, use_graph=True, gather=False)
+            torch.cuda.synchronize()
+            dt_ = torch.tensor([time.perf_counter() - t1], device=dev)
+            if use_dp:
+                torch.distributed.all_reduce(dt_, op=torch.distributed.ReduceOp.MAX)
+            return float(dt_)
+        run(2)                                                                                   # warm-up / caches
+        k0 = 4
+        t_short, t_long = run(k0), run(k0 + args.sample_steps)
+        rate = args.sample_steps / max(t_long - t_short, 1e-9)
+        sample = {"steps_per_s": round(rate, 3), "n": n * world, "denoiser_batch_per_gpu": 2 * n, "guide_w": 2.0, "hipgraph": True,
+                  "encoder_dedup": True, "steps_timed": args.sample_steps, "images_x_steps_per_s": round(rate * n * world, 1)}
         ddpm.train()
 
     cpu = None
@@ -266,7 +281,7 @@ def main():
                           "global_batch": args.batch * world, "bottleneck_k": args.bottleneck_k, "n_classes": 4,
                           "parallelism": "dp%d" % world, "hipgraph": graphed is not None, "samples_per_s": round(value * args.batch, 2)},
                "loss": final_loss, "roofline": roofline, "cpu_baseline": cpu, "sample": sample}
-        print(json.dumps(out))
+        print(json.dumps(out), file=json_out, flush=True)
     if use_dp:
         torch.distributed.destroy_process_group()
 
