@@ -765,6 +765,7 @@ int launch_halo(const ConvP& p, hipStream_t st) {
 // 3x3, stride 1, pad 1, whole image rows of 16/32/64 pixels, 64-channel chunks, byte offsets below 2^31
 bool halo_eligible(const ConvP& p) {
     if (p.T != 9 || p.KW != 3 || p.sy != 1 || p.sx != 1) return false;
+    if (p.N <= 32) return false;                                       // the 3-channel head: a 128-wide tile would be 97 % padding; the gather kernel has 32-wide tiles
     // forward taps (y-1+ky, x-1+kx), or the input-gradient's mirrored traversal (y+1-ky, x+1-kx)
     if (!((p.ty == 1 && p.tx == 1 && p.oy0 == -1 && p.ox0 == -1) || (p.ty == -1 && p.tx == -1 && p.oy0 == 1 && p.ox0 == 1))) return false;
     if (p.Hq != p.Hi || p.Wq != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi || p.osy != 1 || p.osx != 1 || p.ooy != 0 || p.oox != 0) return false;

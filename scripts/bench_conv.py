@@ -24,6 +24,8 @@ SHAPES = [  # (name, B, H, Cin, Cout, k, stride)
     ("64^2 128->32 1x1", 64, 64, 128, 32, 1, 1),
     ("64^2 32->128 1x1", 64, 64, 32, 128, 1, 1),
     ("128^2 256->256 3x3 (cfg-5)", 8, 128, 256, 256, 3, 1),
+    ("64^2 128->8 3x3 (head)", 64, 64, 128, 8, 3, 1),
+    ("64^2 8->128 3x3 (stem)", 64, 64, 8, 128, 3, 1),
 ]
 
 
