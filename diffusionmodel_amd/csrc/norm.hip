@@ -590,7 +590,11 @@ static int gn_slabs(int B, int HW, int C, int G, int V, const void* a, const voi
 // grid of the per-thread-column streaming kernels: >= 8 vectors per thread (the 4 x V channel parameters a
 // thread keeps in registers are then amortised), at most 8 workgroups per CU, at least one pass over a row
 int stream_grid(int64_t nvec, int cv) {
-    int64_t g = (nvec + 256 * 8 - 1) / (256 * 8);
+    // 8 vectors per thread on large tensors; small ones (the 8x8 / 16x16 levels: 0.5 M vectors) would then get one workgroup per
+    // CU and run at 1.6 TB/s: at least ~1024 workgroups as long as a thread keeps 2 vectors
+    int per = 8;
+    while (per > 2 && nvec / (256 * per) < 1024) per /= 2;
+    int64_t g = (nvec + 256 * per - 1) / (256 * per);
     if (g > 2048) g = 2048;
     const int64_t need = (cv + 255) / 256;
     if (g < need) g = need;
@@ -599,7 +603,11 @@ int stream_grid(int64_t nvec, int cv) {
 
 // rows per workgroup of the column-reduction kernels: small matrices get thinner slabs so that the grid
 // still covers the chip
-int cs_rows(int M) { return M >= 65536 ? 128 : (M >= 16384 ? 64 : 32); }
+int cs_rows(int M) {                                  // ~1024 workgroups: 8 ... 256 rows each (a power of two)
+    int r = 8;
+    while (r < 256 && (int64_t)r * 2048 <= M) r *= 2;
+    return r;
+}
 
 template <typename T>
 bool vec_ok(int C, const void* a, const void* b = nullptr, const void* c = nullptr) {
