@@ -44,12 +44,14 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const int64_t* __restri
         const int e = blocks[4 * b], n0 = blocks[4 * b + 1] * 32, c0 = blocks[4 * b + 2] * 32, tt = blocks[4 * b + 3];
         const int64_t* ent = entries + 8 * (int64_t)e;
         const float* src = (const float*)ent[0];
-        const int N = (int)ent[2], Tn = (int)ent[3], C = (int)ent[4], Tt = (int)ent[5], Np = (int)ent[6], dtype = (int)ent[7];
+        const int N = (int)ent[2], Tn = (int)ent[3], C = (int)ent[4], Tt = (int)ent[5], Np = (int)ent[6], dtype = (int)ent[7] & 0xff;
+        const bool src16 = ((int)ent[7] >> 8) != 0;        // the source is the bf16 shadow of the parameter (same element layout): half the read
         const int ts = taps[16 * e + tt];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + ty + 8 * j, c = c0 + tx;
-            tile[ty + 8 * j][tx] = (n < N && c < C) ? src[((size_t)n * Tn + ts) * C + c] : 0.f;
+            const size_t i = ((size_t)n * Tn + ts) * C + c;
+            tile[ty + 8 * j][tx] = (n < N && c < C) ? (src16 ? (float)((const bf16*)src)[i] : src[i]) : 0.f;
         }
         __syncthreads();
 #pragma unroll

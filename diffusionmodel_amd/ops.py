@@ -173,7 +173,11 @@ def refresh_packs():
                 del _T_PACKS[k]
                 continue
             e = len(ents)
-            ents.append((w.data_ptr(), out.data_ptr(), n, t, c, len(taps), np_, dty))
+            sh = getattr(w, "_dm_shadow16", None)         # bf16 copy of the parameter kept current by the fused optimiser step
+            if sh is not None and dty == L.DM_BF16:
+                ents.append((sh.data_ptr(), out.data_ptr(), n, t, c, len(taps), np_, dty | 0x100))
+            else:
+                ents.append((w.data_ptr(), out.data_ptr(), n, t, c, len(taps), np_, dty))
             taps_rows.append(list(taps) + [0] * (16 - len(taps)))
             for tt in range(len(taps)):
                 for ct in range((c + 31) // 32):
@@ -185,7 +189,7 @@ def refresh_packs():
         _T_TABLES["ents"] = torch.tensor(ents, dtype=torch.int64).to(dev)
         _T_TABLES["taps"] = torch.tensor(taps_rows, dtype=torch.int32).to(dev)
         _T_TABLES["blocks"] = torch.tensor(blocks, dtype=torch.int32).to(dev)
-        _T_TABLES["ptrs"] = [e[0] for e in ents]
+        _T_TABLES["ptrs"] = [_T_PACKS[k][0]().data_ptr() for k in _T_PACKS]
         _T_TABLES["keys"] = list(_T_PACKS)
     # a parameter whose storage moved since the tables were built falls back to the lazy per-tensor path
     keys = _T_TABLES["keys"]

@@ -58,6 +58,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     flat.copy_(p.data)
                     p.data = flat
                 self._slots.append((p, off, n))
+        ops._T_TABLES.clear()                       # pack tables built before the shadow existed point at the fp32 masters
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._hyper = torch.zeros(9, dtype=torch.float32, device=dev)
         self._hyper_host = None                       # last values uploaded: re-sent only when a hyper-parameter changes
