@@ -180,8 +180,8 @@ def refresh_packs():
                 ents.append((w.data_ptr(), out.data_ptr(), n, t, c, len(taps), np_, dty))
             taps_rows.append(list(taps) + [0] * (16 - len(taps)))
             for tt in range(len(taps)):
-                for ct in range((c + 31) // 32):
-                    for nt in range((np_ + 31) // 32):
+                for ct in range((c + 63) // 64):
+                    for nt in range((np_ + 63) // 64):
                         blocks.append((e, nt, ct, tt))
         if not ents:
             return

@@ -100,7 +100,7 @@ int dm_unpad_dw(const float* src, float* dst, int N, int T, int C, int Cp, int a
 /* Many dm_pack_wT in one launch (all transposed packs of a model after an optimiser step).  Device tables:
  *   entries[e] = {src, dst, N, T, C, Tt, Np, dtype} as 8 x int64;  taps[e][16] int32 (Tt <= 16);
  *   dtype | 0x100: `src` points to a bf16 copy of the weights in the same element layout (dm_adamw's shadow) instead of fp32;
- *   blocks[b]  = {e, n tile, c tile, tt} int32: one 32 x 32 tile of entry e per workgroup. */
+ *   blocks[b]  = {e, n tile, c tile, tt} int32: one 64 x 64 tile of entry e per workgroup. */
 int dm_pack_multi(const int64_t* entries, const int32_t* taps, const int32_t* blocks, int n_blocks, dm_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------

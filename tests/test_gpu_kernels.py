@@ -593,18 +593,23 @@ def test_batched_pack_device_rng_offset_and_paired_reduce():
     import ctypes as C
     from diffusionmodel_amd._lib import call, ptr, DM_BF16, DM_F32
     # ---- dm_pack_multi: two tensors, different tap subsets / dtypes
-    specs = [(24, 9, 40, [0, 2, 4, 8], 24, torch.bfloat16), (7, 4, 16, [1, 3], 8, torch.float32)]   # N, T, C, taps, Np, dtype
+    # N, T, C, taps, Np, dtype, source = bf16 shadow (flag 0x100)?   (ragged against the 64 x 64 tiles)
+    specs = [(70, 9, 100, [0, 2, 4, 8], 72, torch.bfloat16, False), (7, 4, 16, [1, 3], 8, torch.float32, False),
+             (130, 9, 64, list(range(9)), 136, torch.bfloat16, True)]
     srcs, refs, outs, ents, taps_rows, blocks = [], [], [], [], [], []
-    for e, (N, T, Cc, taps, Np, dtp) in enumerate(specs):
+    for e, (N, T, Cc, taps, Np, dtp, shadow) in enumerate(specs):
         src = torch.randn(N, T, Cc, device=DEV)
+        if shadow:
+            src = src.bfloat16().float()
         ref = torch.empty(Cc, len(taps), Np, device=DEV, dtype=dtp)
         out = torch.full_like(ref, 7.0)
         code = DM_BF16 if dtp == torch.bfloat16 else DM_F32
         call("dm_pack_wT", ptr(src), ptr(ref), code, N, T, Cc, len(taps), (C.c_int32 * len(taps))(*taps), Np)
-        ents.append((src.data_ptr(), out.data_ptr(), N, T, Cc, len(taps), Np, code))
+        src_in = src.bfloat16() if shadow else src
+        ents.append((src_in.data_ptr(), out.data_ptr(), N, T, Cc, len(taps), Np, code | (0x100 if shadow else 0)))
         taps_rows.append(taps + [0] * (16 - len(taps)))
-        blocks += [(e, nt, ct, tt) for tt in range(len(taps)) for ct in range((Cc + 31) // 32) for nt in range((Np + 31) // 32)]
-        srcs.append(src); refs.append(ref); outs.append(out)
+        blocks += [(e, nt, ct, tt) for tt in range(len(taps)) for ct in range((Cc + 63) // 64) for nt in range((Np + 63) // 64)]
+        srcs.append(src_in); refs.append(ref); outs.append(out)
     t_e = torch.tensor(ents, dtype=torch.int64).to(DEV)
     t_t = torch.tensor(taps_rows, dtype=torch.int32).to(DEV)
     t_b = torch.tensor(blocks, dtype=torch.int32).to(DEV)
