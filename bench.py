@@ -258,12 +258,15 @@ def main():
             if use_dp:
                 torch.distributed.all_reduce(dt_, op=torch.distributed.ReduceOp.MAX)
             return float(dt_)
-        run(2)                                                                                   # warm-up / caches
-        k0 = 4
-        t_short, t_long = run(k0), run(k0 + args.sample_steps)
-        rate = args.sample_steps / max(t_long - t_short, 1e-9)
-        sample = {"steps_per_s": round(rate, 3), "n": n * world, "denoiser_batch_per_gpu": 2 * n, "guide_w": 2.0, "hipgraph": True,
-                  "encoder_dedup": True, "steps_timed": args.sample_steps, "images_x_steps_per_s": round(rate * n * world, 1)}
+        try:                                  # the sampling rate is a side figure: a failure here must not lose the train metric
+            run(2)                                                                               # warm-up / caches
+            k0 = 4
+            t_short, t_long = run(k0), run(k0 + args.sample_steps)
+            rate = args.sample_steps / max(t_long - t_short, 1e-9)
+            sample = {"steps_per_s": round(rate, 3), "n": n * world, "denoiser_batch_per_gpu": 2 * n, "guide_w": 2.0, "hipgraph": True,
+                      "encoder_dedup": True, "steps_timed": args.sample_steps, "images_x_steps_per_s": round(rate * n * world, 1)}
+        except Exception as exc:              # noqa: BLE001 — reported in the JSON
+            sample = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         ddpm.train()
 
     cpu = None
