@@ -624,12 +624,18 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
 
 // dw += sum over the pixel splits of the register images in ws: slot e = ((block*8 + wave)*36 + it*9 + t)*64 + lane holds
 // rows n = 4g..4g+3 of the 16x16 tile (it, t) of that wave, column c = il
+// SL = 8: eight threads share an element and take every 8th split (128 splits on the 64x64 layers: one thread per element ran
+// a 16-deep chain of load batches on 144 workgroups — 18 us for 75 MB); the eight partial sums fold through LDS in a fixed order.
+template <int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restrict__ ws, float* __restrict__ dw, float* __restrict__ dbias, int N,
                                                             int C, int nchunks, int blocks, int ldw, int splits) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    constexpr int EPB = 256 / SL;                // elements per workgroup
+    __shared__ f32x4 red[SL > 1 ? 256 : 1];
     const int per_split = blocks * 8 * 36 * 64;
-    if (e >= per_split) {                        // trailing waves, one per n: dbias[n] += the per-workgroup column sums of dy
-        const int n = (e - per_split) >> 6, l = e & 63;
+    const int nmain = per_split / EPB;
+    if ((int)blockIdx.x >= nmain) {              // trailing workgroups, one wave per n: dbias[n] += the per-workgroup column sums of dy
+        const int t = ((int)blockIdx.x - nmain) * 256 + threadIdx.x;
+        const int n = t >> 6, l = t & 63;
         if (dbias == nullptr || n >= N) return;
         const float* wb = (const float*)(ws + (size_t)splits * per_split);
         float v = 0.f;
@@ -641,9 +647,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restri
         if (l == 0) dbias[n] += v;
         return;
     }
+    const int el = threadIdx.x % EPB, sub = threadIdx.x / EPB;
+    const int e = blockIdx.x * EPB + el;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-    for (int k = 0; k < splits; ++k) s += ws[(size_t)k * per_split + e];
+    for (int k = sub; k < splits; k += SL) s += ws[(size_t)k * per_split + e];
+    if constexpr (SL > 1) {
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (sub != 0) return;
+#pragma unroll
+        for (int l = 1; l < SL; ++l) s += red[l * EPB + el];
+    }
     const int lane = e & 63, tile = (e >> 6) % 36, wave = (e / (64 * 36)) & 7, block = e / (64 * 36 * 8);
     const int it = tile / 9, t = tile - it * 9;
     const int nbk = block / nchunks, chunk = block - nbk * nchunks;
@@ -711,8 +726,15 @@ int launch_wgrad_halo(const WgHP& p, hipStream_t st) {
     DM_LAUNCH_CHECK();
     if (p.splits > 1) {
         const int per_split = p.blocks * 8 * 36 * 64;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(per_split / 256 + cdiv(p.N, 4))), dim3(256), 0, st, (const f32x4*)p.ws, p.dw, p.dbias,
-                           p.N, p.C1 + p.C2, p.nchunks, p.blocks, p.ldw, p.splits);
+        if (p.splits >= 32)
+            hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((unsigned)(per_split / 32 + cdiv(p.N, 4))), dim3(256), 0, st, (const f32x4*)p.ws, p.dw, p.dbias,
+                               p.N, p.C1 + p.C2, p.nchunks, p.blocks, p.ldw, p.splits);
+        else if (p.splits >= 8)
+            hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)(per_split / 64 + cdiv(p.N, 4))), dim3(256), 0, st, (const f32x4*)p.ws, p.dw, p.dbias,
+                               p.N, p.C1 + p.C2, p.nchunks, p.blocks, p.ldw, p.splits);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)(per_split / 256 + cdiv(p.N, 4))), dim3(256), 0, st, (const f32x4*)p.ws, p.dw, p.dbias,
+                               p.N, p.C1 + p.C2, p.nchunks, p.blocks, p.ldw, p.splits);
         DM_LAUNCH_CHECK();
     }
     return DM_OK;
