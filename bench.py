@@ -41,53 +41,189 @@ def synthetic_batch(B, S, n_classes, device, seed=0):
     return x.to(device), c.to(device), am.to(device)
 
 
-def cpu_baseline(args):
-    """The CPU oracle (a port of the reference's algorithm, oracle/unet_ref.py) on the host cores:
-    train step at a reduced batch, scaled linearly to the benchmark batch."""
-    from oracle import unet_ref as O
-    torch.manual_seed(0)
-    cores = torch.get_num_threads()
-    nf, S, Bs = args.n_feat, args.size, args.cpu_batch
-    spec = O.context_unet_spec(3, nf, 4, args.bottleneck_k)
-    net_ref = {}
-    for k, shp in spec.items():        # torch-default-like init, enough for timing
+def _rand_state(spec, prefix="nn_model."):
+    """torch-default-like random parameters for an oracle spec (enough for timing)."""
+    P = {}
+    for k, shp in spec.items():
         if k.endswith("num_batches_tracked"):
-            net_ref["nn_model." + k] = torch.zeros((), dtype=torch.long)
+            P[prefix + k] = torch.zeros((), dtype=torch.long)
         elif k.endswith("running_var") or (k.endswith("weight") and len(shp) == 1):
-            net_ref["nn_model." + k] = torch.ones(shp)
+            P[prefix + k] = torch.ones(shp)
         elif len(shp) >= 2:
             fan = 1
             for d in shp[1:]:
                 fan *= d
-            net_ref["nn_model." + k] = (torch.rand(shp) * 2 - 1) / fan ** 0.5
+            P[prefix + k] = (torch.rand(shp) * 2 - 1) / fan ** 0.5
         else:
-            net_ref["nn_model." + k] = torch.zeros(shp)
+            P[prefix + k] = torch.zeros(shp)
+    return P
+
+
+def _cpu_info():
+    model, phys = "unknown", set()
+    try:
+        cur = {}
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if ":" in line:
+                    k, v = [t.strip() for t in line.split(":", 1)]
+                    cur[k] = v
+                    if k == "model name":
+                        model = v
+                elif not line.strip():
+                    if "physical id" in cur and "core id" in cur:
+                        phys.add((cur["physical id"], cur["core id"]))
+                    cur = {}
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return model, (len(phys) or None), usable
+
+
+def _timed(fn, n_timed, warm=1):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(n_timed):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return sum(ts) / len(ts), ts
+
+
+def cpu_baseline(args):
+    """The CPU oracle (a port of the reference's algorithm, oracle/unet_ref.py — the reference's files do not travel to the GPU
+    box) on the host cores, SURVEY §8d / BASELINE.md §3: fp32, (a) the cfg-2 train step = DDPM.forward + backward + clip(1.0) +
+    AdamW at a reduced batch, scaled linearly to the benchmark batch, (b) the cfg-2 CFG sample step (n reduced likewise, w = 2),
+    (c) cfg-1 (MNIST net, B = 64, T = 400) train and sample steps in full.  The thread count is the best of a small sweep (the
+    usable cores, and 64 / 32 when the box has more: 128 SMT threads oversubscribe oneDNN on this workload); 1 warm-up + >= 3
+    timed iterations per leg at that count."""
+    from oracle import unet_ref as O
+    torch.manual_seed(0)
+    model, phys, usable = _cpu_info()
+    nf, S, Bs = args.n_feat, args.size, args.cpu_batch
+    P = _rand_state(O.context_unet_spec(3, nf, 4, args.bottleneck_k))
     params = []
-    for k, v in net_ref.items():
+    for k, v in P.items():
         if v.is_floating_point() and "running" not in k:
             v.requires_grad_(True)
             params.append(v)
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-5)
     sched = O.ddpm_schedules(1e-4, 0.02, 1000)
     x, c, am = synthetic_batch(Bs, S, 4, "cpu")
-    times = []
-    for it in range(1 + args.cpu_iters):
-        t0 = time.perf_counter()
+
+    def train_step():
         ts = torch.randint(1, 1001, (Bs,))
         noise = torch.randn_like(x)
         keep = torch.bernoulli(torch.full((Bs,), 0.9))
         opt.zero_grad()
-        loss = O.ddpm_loss(net_ref, sched, 1000, x, c, am, ts, noise, keep, True)
+        loss = O.ddpm_loss(P, sched, 1000, x, c, am, ts, noise, keep, True)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 1.0)
         opt.step()
-        if it > 0:
-            times.append(time.perf_counter() - t0)
-    t = sum(times) / len(times)
+
+    cands = sorted({t for t in (usable, phys or usable, 64, 32) if t and t <= usable}, reverse=True)
+    sweep = {}
+    for t in cands:                                   # 1 warm-up + 1 timed iteration per candidate
+        torch.set_num_threads(t)
+        sweep[t] = round(_timed(train_step, 1)[0], 3)
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    n_it = max(3, args.cpu_iters)
+    t_train, all_train = _timed(train_step, n_it, warm=0)
     scale = args.batch / Bs
-    return {"value": round(1.0 / (t * scale), 5), "unit": "denoiser-steps/s (train, B=%d)" % args.batch, "cores": cores,
-            "kind": "port", "sample": f"oracle train step (fwd+bwd+clip+AdamW) fp32 at B={Bs} x{scale:g} scaled, "
-                                      f"{args.cpu_iters} timed iters, {t:.2f} s/iter"}
+
+    # (b) cfg-2 sample step: one iteration of DDPM.sample's loop (denoiser on the CFG-doubled batch + update), eval mode
+    xs = torch.randn(Bs, 3, S, S)
+    zs = [torch.randn(Bs, 3, S, S)]
+
+    def sample_step():
+        with torch.no_grad():
+            O.ddpm_sample(P, sched, 1000, 4, xs, zs, 2.0, steps=1)
+    t_samp, _ = _timed(sample_step, n_it)
+
+    # (c) cfg-1: MNIST_script.py net, 28x28, F=64, T=400, B=64 (train) / n=60 (sample: labels cycle over 10 classes)
+    PM = _rand_state(O.mnist_unet_spec(1, 64, 10, 7))
+    pm = []
+    for k, v in PM.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+            pm.append(v)
+    optm = torch.optim.Adam(pm, lr=1e-4)
+    sched_m = O.ddpm_schedules(1e-4, 0.02, 400)
+    xm, cm = torch.rand(64, 1, 28, 28), torch.randint(0, 10, (64,))
+
+    def mnist_train():
+        ts = torch.randint(1, 401, (64,))
+        noise = torch.randn_like(xm)
+        drop = torch.bernoulli(torch.full((64,), 0.1))
+        optm.zero_grad()
+        O.mnist_ddpm_loss(PM, sched_m, 400, xm, cm, ts, noise, drop, True).backward()
+        optm.step()
+    t_mt, _ = _timed(mnist_train, n_it)
+    xsm, zsm = torch.randn(60, 1, 28, 28), [torch.randn(60, 1, 28, 28)]
+
+    def mnist_sample():
+        with torch.no_grad():
+            O.ddpm_sample(PM, sched_m, 400, 10, xsm, zsm, 2.0, steps=1, net=O.mnist_context_unet)
+    t_ms, _ = _timed(mnist_sample, n_it)
+
+    return {"value": round(1.0 / (t_train * scale), 5), "unit": "denoiser-steps/s (train, B=%d)" % args.batch, "cores": best,
+            "kind": "port", "cpu_model": model, "physical_cores": phys, "usable_threads": usable,
+            "thread_sweep_s_per_iter": {str(k): v for k, v in sweep.items()},
+            "sample": f"oracle train step (fwd+bwd+clip+AdamW) fp32 at B={Bs} x{scale:g} scaled, {n_it} timed iters at {best} threads "
+                      f"({', '.join('%.2f' % v for v in all_train)} s)",
+            "train_s_per_iter_at_sample_batch": round(t_train, 3),
+            "sample_step": {"value": round(1.0 / (t_samp * scale), 5), "unit": "denoiser-steps/s (CFG sample, n=%d, w=2)" % args.batch,
+                            "sample": f"one sample() iteration at n={Bs} (denoiser batch {2 * Bs}) x{scale:g} scaled, {n_it} timed iters, {t_samp:.2f} s/iter"},
+            "cfg1_mnist": {"train_steps_per_s": round(1.0 / t_mt, 3), "sample_steps_per_s": round(1.0 / t_ms, 3),
+                           "sample": f"MNIST net 28x28 F=64 T=400: train B=64 (fwd+bwd+Adam) {t_mt * 1e3:.0f} ms, sample n=60 (CFG batch 120) "
+                                     f"{t_ms * 1e3:.0f} ms; {n_it} timed iters each, full size (no scaling)"}}
+
+
+def self_launch(argv, n):
+    """`python bench.py --gpus N` outside torchrun: this parent makes NO GPU call (torch.cuda.device_count() does not initialise
+    HIP on this image); it starts N fresh child processes — one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set —
+    relays rank 0's JSON line and exits with the first non-zero child code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DM_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = [ln for ln in (out or "").splitlines() if ln.startswith("{")]
+    if line:
+        print(line[-1], flush=True)
+    bad = [c for c in codes if c]
+    if bad or not line:
+        print(f"[bench] child exit codes {codes}", file=sys.stderr)
+        raise SystemExit(bad[0] if bad else 1)
+
+
+def launcher_selftest(args):
+    """--launch-selftest: what a child of the self-launcher does with a gloo group on the CPU — joins, agrees on the world size and
+    reports it.  Exists so that the launcher (ports, environment, relay of rank 0's line) is covered by a CPU test."""
+    import torch.distributed as dist
+    from diffusionmodel_amd import parallel
+    rank, world, local = parallel.init_from_env("gloo", force=True)
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    devs = [None] * world
+    dist.all_gather_object(devs, f"cpu:{local}")
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": args.gpus, "ranks": dist.get_world_size(), "sum": float(t), "devices": devs}), flush=True)
+    dist.destroy_process_group()
 
 
 def main():
@@ -107,7 +243,8 @@ def main():
     ap.add_argument("--sample-steps", dest="sample_steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
     ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=8)
-    ap.add_argument("--cpu-iters", dest="cpu_iters", type=int, default=2)
+    ap.add_argument("--cpu-iters", dest="cpu_iters", type=int, default=3)
+    ap.add_argument("--launch-selftest", dest="launch_selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--buckets", type=int, default=6)
     ap.add_argument("--graph", dest="graph", action="store_true",
                     help="replay the train step as one captured hipGraph (single process).  Same device-side time as eager launches "
@@ -118,11 +255,24 @@ def main():
                     help="run the RCCL gradient all-reduce path even with one rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torchrun: be the launcher (no GPU call has been made in this process)
+        if not args.launch_selftest:
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                raise SystemExit(f"--gpus {args.gpus} but only {have} HIP device(s) are visible")
+        os.dup2(json_out.fileno(), 1)
+        return self_launch(sys.argv[1:], args.gpus)
+    if args.launch_selftest:
+        os.dup2(json_out.fileno(), 1)
+        return launcher_selftest(args)
+
     import diffusionmodel_amd as D
     from diffusionmodel_amd import ops, parallel
     rank, world, local = parallel.init_from_env("nccl", force=args.force_dp)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         "(or run `python bench.py --gpus N` without WORLD_SIZE set: it starts its own ranks)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -189,6 +339,11 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
     final_loss = float(loss.item())
+    devices = [f"cuda:{local}"]
+    if use_dp:
+        devices = [None] * torch.distributed.get_world_size()
+        torch.distributed.all_gather_object(devices, f"cuda:{local} ({torch.cuda.get_device_properties(local).name})")
+    ranks_seen = torch.distributed.get_world_size() if use_dp else 1
 
     # ---- roofline of the dominant kernel family (implicit-GEMM conv fwd/dgrad + wgrad) from the events
     fl = {"conv_igemm": [0.0, 0.0, 0], "conv_wgrad": [0.0, 0.0, 0]}
@@ -276,7 +431,7 @@ def main():
     if rank == 0:
         value = world * args.steps / elapsed
         out = {"metric": f"denoiser-steps/sec (train fwd+bwd+clip+AdamW, {args.size}x{args.size}, B={args.batch}/GPU)", "value": round(value, 4),
-               "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "unit": "steps/s", "n_gpus": world, "ranks": ranks_seen, "devices": devices, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "new_scripy.py ContextUnet %dx%d n_feat=%d T=1000 %s, train step batch=%d per GPU (BASELINE configs[%d])"

@@ -67,6 +67,7 @@ class DDPM(_HipBlock):
         self.compute_dtype = self.nn_model.compute_dtype
         self._cfg6 = (None, None)
         self._rng_calls = 0
+        self._sample_calls = 0        # unseeded sample() calls so far: each draws from its own Philox key
         self.rng_seed = None          # None -> torch.initial_seed()
 
     # ------------------------------------------------------------------------------------------
@@ -78,6 +79,18 @@ class DDPM(_HipBlock):
 
     def _seed(self):
         return int(torch.initial_seed() if self.rng_seed is None else self.rng_seed) & 0x7FFFFFFFFFFFFFFF
+
+    def _sample_seed(self):
+        """Philox key of the next UNSEEDED sample() call: the instance seed mixed (splitmix64) with a sampler domain tag and the
+        number of unseeded calls so far.  The reference draws fresh torch.randn noise on every call (new_scripy.py:445,465), so two
+        calls must not return the same images, and the sampler's stream must not coincide with the training noise, which uses the
+        bare instance seed with the forward-call count as the counter's high word."""
+        z = (self._seed() ^ 0x5A4D504C45520000) + 0x9E3779B97F4A7C15 * (self._sample_calls + 1)
+        self._sample_calls += 1
+        z &= 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return (z ^ (z >> 31)) & 0x7FFFFFFFFFFFFFFF
 
     def forward(self, x, c, attn_mask, *, ts=None, noise=None, ctx_mask=None):
         """Training loss (new_scripy.py:401-439).  x (B,3,H,W) fp32, c (B,) int, attn_mask (B,H,W)."""
@@ -139,7 +152,7 @@ class DDPM(_HipBlock):
         if first_sample < 0 or first_sample + n_sample > total:
             raise DmError(f"samples [{first_sample}, {first_sample + n_sample}) are not inside a batch of {total}")
         dev = torch.device(device)
-        seed = self._seed() if seed is None else int(seed)
+        seed = self._sample_seed() if seed is None else int(seed)
         per = 1
         for d in size:
             per *= int(d)

@@ -159,7 +159,7 @@ class DDPM(_DDPM):
     def sample(self, n_sample, size, device, guide_w=0.0, *, x_T=None, zs=None, dedup=True, seed=None, steps=None):
         net = self.nn_model
         dev = torch.device(device)
-        seed = self._seed() if seed is None else int(seed)
+        seed = self._sample_seed() if seed is None else int(seed)       # unseeded calls draw fresh noise, like the reference
         x_i = (x_T.to(dev).float().contiguous().clone() if x_T is not None else ops.randn((n_sample,) + tuple(size), dev, seed, 0))
         c_i = torch.arange(0, self.n_classes, device=dev).repeat(n_sample // self.n_classes).repeat(2)
         mask = torch.zeros(2 * n_sample, device=dev)

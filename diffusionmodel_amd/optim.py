@@ -6,7 +6,7 @@ accumulate straight into it (`param.main_grad`), the few hundred small parameter
 are gathered by ONE multi-tensor launch, and one sum-of-squares + one AdamW launch finish the step.
 The flat gradient buffer is also what the data-parallel all-reduce works on (parallel.py).
 """
-import math
+import weakref
 
 import torch
 
@@ -64,9 +64,15 @@ class FusedAdamW(torch.optim.Optimizer):
         self._hyper_host = None                       # last values uploaded: re-sent only when a hyper-parameter changes
         self._table = None                            # (pinned host, device) pointer table of gather_grads
         self._step_dev = torch.zeros(1, dtype=torch.int64, device=dev)   # step count on the device (bias corrections)
+        self._captured_tables = []                    # pointer tables a stream capture baked into a graph: never reused
         self.refresh_shadow()
         ops.bump_weight_epoch()
-        ops.ARENA_ENABLED[0] = True                  # step() recycles the gradient scratch arena
+        # the gradient scratch arena is recycled by step(); that is only sound while ONE optimiser consumes the gradients of
+        # this process (a second live optimiser's step would zero accumulators the first one has not read yet)
+        _LIVE.add(self)
+        ops.ARENA_ENABLED[0] = len(_LIVE) == 1
+        if not ops.ARENA_ENABLED[0]:
+            ops.ZERO_ARENA.recycle()
 
     def refresh_shadow(self):
         """Recompute the whole bf16 shadow from the fp32 masters (construction, after a parameter broadcast or any
@@ -107,10 +113,17 @@ class FusedAdamW(torch.optim.Optimizer):
                                 torch.empty((cap, 3), dtype=torch.int64, device=self.flat_g.device), None] for _ in range(4)]
                 self._table_i = 0
             capturing = torch.cuda.is_current_stream_capturing()
-            slot = self._table[self._table_i]
-            self._table_i = (self._table_i + 1) % 4
-            if slot[2] is not None and not capturing:
-                slot[2].synchronize()                 # the copy that last read this host buffer has run
+            if capturing:
+                # the upload becomes a graph node that re-reads its pinned source on every replay: the capture gets a table of its
+                # own (host and device) that lives as long as the optimiser and is never recycled by later eager steps
+                slot = [torch.empty((len(rows), 3), dtype=torch.int64).pin_memory(),
+                        torch.empty((len(rows), 3), dtype=torch.int64, device=self.flat_g.device), None]
+                self._captured_tables.append(slot)
+            else:
+                slot = self._table[self._table_i]
+                self._table_i = (self._table_i + 1) % 4
+                if slot[2] is not None:
+                    slot[2].synchronize()             # the copy that last read this host buffer has run
             host, table = slot[0], slot[1]
             host[:len(rows)] = torch.tensor(rows, dtype=torch.int64)
             table[:len(rows)].copy_(host[:len(rows)], non_blocking=True)
@@ -120,7 +133,8 @@ class FusedAdamW(torch.optim.Optimizer):
             call("dm_scatter_copy", ptr(table), len(rows), 1)
         for p, _, _ in self._slots:
             p.grad = None
-        ops.ZERO_ARENA.recycle()                     # every small gradient accumulator has been copied out: one fill re-zeroes them
+        if ops.ARENA_ENABLED[0]:
+            ops.ZERO_ARENA.recycle()                 # every small gradient accumulator has been copied out: one fill re-zeroes them
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -153,3 +167,77 @@ class FusedAdamW(torch.optim.Optimizer):
     def grad_norm(self):
         """Global gradient norm of the last step (device tensor, no host sync)."""
         return self._sumsq.sqrt() * self.grad_scale
+
+    # ------------------------------------------------------------------------------------------
+    # torch.optim.AdamW's state_dict() schema (what the reference checkpoints hold: new_scripy.py:736-743 saves optim.state_dict())
+    _GROUP_DEFAULTS = dict(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                           decoupled_weight_decay=True)
+
+    def _logical(self, flat, p, off, n):
+        """The slice of a flat state buffer that belongs to `p`, as a fresh tensor in p's logical shape."""
+        if p.dim() == 4:
+            O, I, kh, kw = p.shape
+            return flat[off:off + n].view(O, kh, kw, I).permute(0, 3, 1, 2).contiguous()
+        return flat[off:off + n].view(p.shape).clone()
+
+    def state_dict(self):
+        """{"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]} exactly as torch.optim.AdamW lays it out
+        (per-parameter tensors in the parameters' logical shapes, `step` a float32 scalar tensor, empty state before the first
+        step), so a checkpoint written here resumes under torch's AdamW and vice versa."""
+        g0 = self.param_groups[0]
+        group = {k: g0[k] for k in ("lr", "betas", "eps", "weight_decay")}
+        for k, v in self._GROUP_DEFAULTS.items():
+            group[k] = g0.get(k, v)
+        for k in g0:                                   # e.g. initial_lr written by an lr scheduler
+            if k not in group and k != "params":
+                group[k] = g0[k]
+        group["params"] = list(range(len(self._slots)))
+        state = {}
+        if self._step > 0:
+            for i, (p, off, n) in enumerate(self._slots):
+                state[i] = {"step": torch.tensor(float(self._step), dtype=torch.float32),
+                            "exp_avg": self._logical(self.exp_avg, p, off, n),
+                            "exp_avg_sq": self._logical(self.exp_avg_sq, p, off, n)}
+        return {"state": state, "param_groups": [group]}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self._slots):
+            raise DmError(f"FusedAdamW.load_state_dict: expected one param group of {len(self._slots)} parameters, got "
+                          f"{[len(g['params']) for g in groups]}")
+        g0 = self.param_groups[0]
+        for k, v in groups[0].items():
+            if k != "params":
+                g0[k] = tuple(v) if k == "betas" else v
+        state = sd.get("state", {})
+        steps = set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for i, (p, off, n) in enumerate(self._slots):
+            st = state.get(i, state.get(str(i)))
+            if st is None:
+                continue
+            steps.add(int(float(st["step"])))
+            for key, flat in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+                v = st[key]
+                if tuple(v.shape) != tuple(p.shape):
+                    raise DmError(f"FusedAdamW.load_state_dict: {key} of parameter {i} has shape {tuple(v.shape)}, expected {tuple(p.shape)}")
+                v = v.to(device=flat.device, dtype=torch.float32)
+                dst = flat[off:off + n]
+                if p.dim() == 4:
+                    O, I, kh, kw = p.shape
+                    dst.view(O, kh, kw, I).copy_(v.permute(0, 2, 3, 1))
+                else:
+                    dst.view(p.shape).copy_(v)
+        if len(steps) > 1:
+            raise DmError(f"FusedAdamW.load_state_dict: parameters disagree on the step count ({sorted(steps)}); the fused kernel keeps one")
+        self._step = steps.pop() if steps else 0
+        self._step_dev.fill_(self._step)
+        self._hyper_host = None
+        self.refresh_shadow()                          # the masters were most likely just loaded too
+        ops.bump_weight_epoch()
+        ops.refresh_packs()
+
+
+_LIVE = weakref.WeakSet()       # optimisers alive in this process (the gradient scratch arena serves exactly one)

@@ -31,7 +31,53 @@ def init_from_env(backend=None, force=False):
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        guard_shared_device(local)
     return rank, world, local
+
+
+def _device_identity(local):
+    """(host, physical device) of the HIP device this rank will use — enough to tell whether two ranks share one GPU."""
+    import socket
+    vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "")))
+    ident = None
+    if torch.cuda.is_available() and local < torch.cuda.device_count():
+        props = torch.cuda.get_device_properties(local)
+        ident = str(getattr(props, "uuid", "")) or None
+        bus = getattr(props, "pci_bus_id", None)
+        if bus is not None:
+            ident = f"{ident}|bus{bus}|dev{getattr(props, 'pci_device_id', '')}|dom{getattr(props, 'pci_domain_id', '')}"
+    if ident is None:
+        ident = f"visible[{vis}]#{local}"
+    return socket.gethostname(), ident
+
+
+def guard_shared_device(local, group=None, identity=None):
+    """Two ranks on ONE GPU time-share it, and on this driver stack a workgroup that holds more than 64 KiB of LDS does not
+    survive being preempted for another process (7 of 88 backward passes corrupted with the 156-KiB halo kernels,
+    0 of 60 with every kernel held to <= 64 KiB, 0 of 40 for a process that owns the GPU).  So when the ranks of this job do not
+    each have a device of their own, every rank switches the library to its <= 64-KiB kernel variants and says so on stderr —
+    slower (gather kernels instead of the halo-resident ones), never silently wrong.  Returns True when the guard engaged."""
+    import sys
+    mine = identity if identity is not None else _device_identity(local)
+    everyone = [None] * dist.get_world_size(group)
+    dist.all_gather_object(everyone, mine, group=group)
+    shared = len(set(everyone)) < len(everyone)
+    if shared:
+        from . import _lib as L
+        SHARED_DEVICE[0] = True
+        if torch.cuda.is_available():
+            lib = L.load()
+            if lib.dm_set_conv_variant(2) != 0 or lib.dm_set_wgrad_variant(2) != 0:
+                raise DmError(lib.dm_last_error().decode())
+        if dist.get_rank(group) == 0:
+            print(f"[diffusionmodel_amd] {len(everyone)} ranks share {len(set(everyone))} device(s): selecting the <= 64-KiB-LDS "
+                  "kernel variants (DM_CONV_VARIANT=2, DM_WGRAD_VARIANT=2); workgroups with more LDS are not preemption-safe "
+                  "between processes on this stack. Use one process per GPU for full speed.", file=sys.stderr, flush=True)
+    return shared
+
+
+SHARED_DEVICE = [False]
 
 
 def bucket_bounds(total, n_buckets, align=1024):

@@ -276,6 +276,8 @@ def main():
     gen_ddpm_sample(R, "sample64_T3_w0", 64, 4, 3, 8, 0.0)
     gen_mnist(M)
     gen_metrics_and_masks(R)
+    gen_bf16_autocast(R)
+    gen_train3(R)
     # key schema of the full-size nets (shapes only; no tensors are instantiated for the big ones)
     SCHEMA["ddpm_keys_F32_k4"] = [(k, list(v.shape)) for k, v in
                                   R.DDPM(make_ref_unet(R, 32, 4, 4), (1e-4, 0.02), 1000, "cpu").state_dict().items()]
@@ -338,8 +340,196 @@ def gen_metrics_and_masks(R):
     print("metrics", out["ssim"], out["psnr"])
 
 
+def _per_child_grads(net):
+    """{child: flat float64 gradient vector} over the top-level children of a net (zeros where a parameter got no gradient)."""
+    d = {}
+    for cname, child in net.named_children():
+        vs = [(p.grad if p.grad is not None else torch.zeros_like(p)).detach().double().reshape(-1) for p in child.parameters()]
+        if vs:
+            d[cname] = torch.cat(vs)
+    return d
+
+
+def _cos(a, b):
+    return float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
+
+
+def gen_bf16_autocast(R, S=64, k=4, nf=32, ncls=4):
+    """The REFERENCE under torch.autocast("cpu", dtype=torch.bfloat16) — the precision mode BASELINE configs[1] is quoted in
+    (new_scripy.py:784 wraps DDPM.forward in autocast) — next to the same reference code in float64, on the unet32_64 and
+    ddpm_fwd64 cases.  Pins what "bf16 parity" means: the reference's own bf16 error (eps MSE, loss, per-child gradient
+    norm ratio and cosine against fp64) is the yardstick the HIP bf16 path is held to (tests/test_gpu_bf16.py)."""
+    out = {}
+    # ---- (a) denoiser alone, eval + train
+    tag, B = "unet32_64", 2
+    net = make_ref_unet(R, nf, ncls, k)
+    load_synth(net)
+    init = {kk: v.clone() for kk, v in net.state_dict().items()}
+    x = synth.synth_input(tag + ".x", (B, 3, S, S))
+    c = torch.tensor([(3 * i + 1) % ncls for i in range(B)])
+    t = torch.tensor([(0.37 + 0.41 * i) % 1.0 for i in range(B)])
+    mk = torch.tensor([float((i + 1) % 2) for i in range(B)])
+    probe = synth.synth_input(tag + ".probe", (B, 3, S, S))
+    for train in (False, True):
+        mode = "train" if train else "eval"
+        # float64 run of the reference: eps, loss, per-child gradients
+        net.load_state_dict(init)
+        net.double()
+        net.train(train)
+        net.zero_grad()
+        e64 = net(x.double(), c, t.double(), mk.double())
+        l64 = (e64 * probe.double()).mean()
+        l64.backward()
+        g64 = _per_child_grads(net)
+        net.float()
+        net.load_state_dict(init)
+        net.train(train)
+        net.zero_grad()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            e16 = net(x, c, t, mk)
+            l16 = (e16.float() * probe).mean()
+        l16.backward()
+        g16 = _per_child_grads(net)
+        e16 = e16.detach().float()
+        out[f"unet.{mode}.eps_bf16"] = e16.numpy()
+        out[f"unet.{mode}.eps64"] = e64.detach().numpy()
+        out[f"unet.{mode}.mse_bf16_vs_64"] = np.float64(((e16.double() - e64.detach()) ** 2).mean().item())
+        out[f"unet.{mode}.maxabs_bf16_vs_64"] = np.float64((e16.double() - e64.detach()).abs().max().item())
+        out[f"unet.{mode}.power64"] = np.float64((e64.detach() ** 2).mean().item())
+        out[f"unet.{mode}.loss64"] = np.float64(l64.item())
+        out[f"unet.{mode}.loss_bf16"] = np.float64(l16.item())
+        for cn in g64:
+            out[f"unet.{mode}.gn64.{cn}"] = np.float64(g64[cn].norm().item())
+            out[f"unet.{mode}.gn_bf16.{cn}"] = np.float64(g16[cn].norm().item())
+            out[f"unet.{mode}.cos_bf16.{cn}"] = np.float64(_cos(g16[cn], g64[cn]))
+        print("bf16 autocast", mode, "mse", out[f"unet.{mode}.mse_bf16_vs_64"], "max", out[f"unet.{mode}.maxabs_bf16_vs_64"],
+              "loss", l64.item(), l16.item(), "min cos", min(out[f"unet.{mode}.cos_bf16.{cn}"] for cn in g64 if cn != "local_enhance"))
+    # ---- (b) DDPM.forward with the injected draws (same case as ddpm_fwd64.npz)
+    tag, B, n_T = "ddpm_fwd64", 4, 1000
+    net = make_ref_unet(R, nf, ncls, k)
+    ddpm = R.DDPM(net, (1e-4, 0.02), n_T, "cpu", drop_prob=0.1)
+    load_synth(ddpm)
+    for kk, v in R.ddpm_schedules(1e-4, 0.02, n_T).items():
+        getattr(ddpm, kk).copy_(v)
+    init = {kk: v.clone() for kk, v in ddpm.state_dict().items()}
+    x = synth.synth_input(tag + ".x", (B, 3, S, S))
+    c = torch.tensor([(i + 2) % ncls for i in range(B)])
+    am = synth.synth_attn_mask(B, S)
+    inj = Inject(tag, n_T)
+    for train in (True, False):
+        mode = "train" if train else "eval"
+        res = {}
+        for prec in ("64", "bf16"):
+            ddpm.float()
+            ddpm.load_state_dict(init)
+            net.__dict__.pop("forward", None)
+            if prec == "64":
+                ddpm.double()
+                # harness only: DDPM.forward hands the net a float32 t and keep-mask (new_scripy.py:413-415); the float64 run casts them
+                net.forward = lambda xx, cc, tt, mm, _f=type(net).forward, _n=net: _f(_n, xx, cc, tt.double(), mm.double())
+            ddpm.train(train)
+            ddpm.zero_grad()
+            xin = x.double() if prec == "64" else x
+            with mock.patch.object(torch, "randint", inj.randint), \
+                    mock.patch.object(torch, "randn_like", lambda v, **kw: inj.randn_like(v).to(v.dtype)), \
+                    mock.patch.object(torch, "bernoulli", lambda p, **kw: inj.bernoulli(p).to(p.dtype)):
+                if prec == "bf16":
+                    with torch.autocast("cpu", dtype=torch.bfloat16):      # new_scripy.py:784
+                        loss = ddpm(xin, c, am)
+                else:
+                    loss = ddpm(xin, c, am.double())
+            res[prec] = float(loss.item())
+            if train:
+                loss.backward()
+                res["g" + prec] = _per_child_grads(ddpm.nn_model)
+        ddpm.float()
+        net.__dict__.pop("forward", None)
+        out[f"ddpm.{mode}.loss64"], out[f"ddpm.{mode}.loss_bf16"] = np.float64(res["64"]), np.float64(res["bf16"])
+        if train:
+            for cn in res["g64"]:
+                out[f"ddpm.train.gn64.{cn}"] = np.float64(res["g64"][cn].norm().item())
+                out[f"ddpm.train.gn_bf16.{cn}"] = np.float64(res["gbf16"][cn].norm().item())
+                out[f"ddpm.train.cos_bf16.{cn}"] = np.float64(_cos(res["gbf16"][cn], res["g64"][cn]))
+        print("bf16 autocast ddpm", mode, res["64"], res["bf16"])
+    np.savez_compressed(os.path.join(OUT, "bf16_autocast.npz"), **out)
+
+
+def gen_train3(R, S=64, k=4, nf=32, ncls=4, B=2, n_T=1000, accum=2, n_opt=3, lr=1e-3, wd=1e-2):
+    """Three optimiser steps of the reference's train loop (new_scripy.py:777-803: loss / ACCUM_STEPS, backward, every ACCUM_STEPS
+    micro-batches clip_grad_norm_(1.0) + AdamW.step + zero_grad) on the CPU in fp32, with every random draw injected
+    (micro-batch m uses the tags train3.m<m>.*).  Pins the training driver + fused optimiser: per-micro-batch losses, the
+    pre-clip gradient norm of every step, per-child parameter norms after the last step, torch's AdamW state of three
+    parameters, and two parameter tensors in full."""
+    net = make_ref_unet(R, nf, ncls, k)
+    ddpm = R.DDPM(net, (1e-4, 0.02), n_T, "cpu", drop_prob=0.1)
+    load_synth(ddpm)
+    for kk, v in R.ddpm_schedules(1e-4, 0.02, n_T).items():
+        getattr(ddpm, kk).copy_(v)
+    ddpm.train()
+    optim = torch.optim.AdamW(ddpm.parameters(), lr=lr, weight_decay=wd)
+    old = R.Cfg.ACCUM_STEPS
+    R.Cfg.ACCUM_STEPS = accum
+    out = {"losses": [], "grad_norms": []}
+    try:
+        optim.zero_grad()
+        for m in range(accum * n_opt):
+            tag = f"train3.m{m}"
+            x = synth.synth_input(tag + ".x", (B, 3, S, S))
+            c = torch.tensor([(m + i) % ncls for i in range(B)])
+            am = synth.synth_attn_mask(B, S)
+            inj = Inject(tag, n_T)
+            ts = torch.tensor([1 + (313 * (i + 2 * m) + 96) % n_T for i in range(B)])
+            keep = torch.tensor([float(((i + m) % 3) != 1) for i in range(B)])
+            with mock.patch.object(torch, "randint", lambda *a, **kw: ts), mock.patch.object(torch, "randn_like", inj.randn_like), \
+                    mock.patch.object(torch, "bernoulli", lambda p, **kw: keep):
+                loss = ddpm(x, c, am) / R.Cfg.ACCUM_STEPS                                   # :785-786
+            out["losses"].append(loss.item() * R.Cfg.ACCUM_STEPS)                          # :789
+            loss.backward()
+            if (m + 1) % R.Cfg.ACCUM_STEPS == 0:                                           # :795-803
+                out["grad_norms"].append(float(torch.nn.utils.clip_grad_norm_(ddpm.parameters(), 1.0)))
+                optim.step()
+                optim.zero_grad()
+            out[f"ts.{m}"], out[f"keep.{m}"] = ts.numpy(), keep.numpy()
+    finally:
+        R.Cfg.ACCUM_STEPS = old
+    res = {"losses": np.array(out["losses"]), "grad_norms": np.array(out["grad_norms"]),
+           "hyper": np.array([lr, wd, accum, n_opt, B])}
+    for m in range(accum * n_opt):
+        res[f"ts.{m}"], res[f"keep.{m}"] = out[f"ts.{m}"], out[f"keep.{m}"]
+    for cn, child in ddpm.nn_model.named_children():
+        ps = [p.detach().double().reshape(-1) for p in child.parameters()]
+        if ps:
+            res[f"pnorm.{cn}"] = np.float64(torch.cat(ps).norm().item())
+    named = dict(ddpm.named_parameters())
+    for pn in ("nn_model.out.3.weight", "nn_model.down2.down.0.weight", "nn_model.ca2.gamma_h", "nn_model.time_emb1.model.0.bias"):
+        res[f"p.{pn}"] = named[pn].detach().numpy()
+        st = optim.state[named[pn]]
+        res[f"m.{pn}"], res[f"v.{pn}"] = st["exp_avg"].numpy(), st["exp_avg_sq"].numpy()
+        res[f"step.{pn}"] = np.float64(float(st["step"]))
+    sd = ddpm.state_dict()
+    for bn in ("nn_model.init_conv.conv1.1.running_mean", "nn_model.up4.model.2.conv2.1.running_var"):
+        res[f"buf.{bn}"] = sd[bn].numpy().copy()
+    res["nbt"] = np.int64(int(sd["nn_model.init_conv.conv1.1.num_batches_tracked"]))
+    # torch's optimizer.state_dict() layout, for the FusedAdamW.state_dict() schema test
+    osd = optim.state_dict()
+    SCHEMA["adamw_state_dict"] = {"param_group_keys": sorted(osd["param_groups"][0].keys()), "n_params": len(osd["param_groups"][0]["params"]),
+                                  "state_keys": sorted(osd["state"][0].keys()),
+                                  "state0": {kk: (list(v.shape), str(v.dtype)) for kk, v in osd["state"][0].items()}}
+    np.savez_compressed(os.path.join(OUT, "train3.npz"), **res)
+    print("train3 losses", res["losses"], "grad norms", res["grad_norms"])
+
+
 if __name__ == "__main__":
     if os.environ.get("DM_GOLDEN_ONLY") == "metrics":
         gen_metrics_and_masks(_refload.load("new_scripy"))
+    elif os.environ.get("DM_GOLDEN_ONLY") == "r02":        # the round-2 additions only (schema.json gets the new key merged in)
+        R_ = _refload.load("new_scripy")
+        gen_bf16_autocast(R_)
+        gen_train3(R_)
+        with open(os.path.join(OUT, "schema.json")) as f:
+            full = json.load(f)
+        full.update(SCHEMA)
+        with open(os.path.join(OUT, "schema.json"), "w") as f:
+            json.dump(full, f, indent=0)
     else:
         main()

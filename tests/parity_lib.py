@@ -1,0 +1,331 @@
+"""Measurements behind the bf16 / training-trajectory parity tests (tests/test_gpu_bf16.py) and behind
+profiles/r02_parity.json (scripts/parity_report.py writes what these functions return).  TEST INFRASTRUCTURE.
+
+Yardsticks:
+* tests/golden/bf16_autocast.npz — the REFERENCE run under torch.autocast("cpu", bfloat16) next to the same code in float64
+  (make_golden.py:gen_bf16_autocast): its eps MSE, loss and per-child gradient norm / cosine say how far bf16 moves the
+  reference itself; the HIP bf16 path is held to a small multiple of that;
+* tests/golden/train3.npz — three optimiser steps of the reference's train loop (accumulation 2, clip 1.0, torch AdamW) on
+  injected draws;
+* the CPU oracle (oracle/unet_ref.py, pinned to the reference by the other fixtures) in float64 / float32 for per-parameter
+  gradients and for the F=128 case no fixture covers.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import synth, unet_ref as O
+
+DEV = "cuda:0"
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SCHEMA = json.load(open(os.path.join(G, "schema.json")))
+si = synth.synth_input
+
+
+def npz(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def _cos(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+
+
+def child_grad_vectors(net, prefix=""):
+    """{top-level child: flat float64 gradient} of an nn.Module after backward (missing gradients count as zeros)."""
+    out = {}
+    for cn, ch in net.named_children():
+        vs = [(p.grad if p.grad is not None else torch.zeros_like(p)).detach().double().reshape(-1).cpu() for p in ch.parameters()]
+        if vs:
+            out[cn] = torch.cat(vs).numpy()
+    return out
+
+
+def oracle_child_vectors(P, names_by_child):
+    return {cn: np.concatenate([(P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])).double().reshape(-1).numpy() for k in ks])
+            for cn, ks in names_by_child.items()}
+
+
+def _names_by_child(net, prefix=""):
+    d = {}
+    for cn, ch in net.named_children():
+        ks = [f"{prefix}{cn}.{k}" for k, _ in ch.named_parameters()]
+        if ks:
+            d[cn] = ks
+    return d
+
+
+def synth_state(tag, dtype=torch.float32, grad=True):
+    P = {}
+    for k, s in SCHEMA[tag]:
+        v = synth.synth_tensor(k, tuple(s))
+        if v.is_floating_point():
+            v = v.to(dtype)
+            if grad and "running" not in k:
+                v.requires_grad_(True)
+        P[k] = v
+    return P
+
+
+def hip_unet(tag, dtype, k=4, F=32):
+    import diffusionmodel_amd as D
+    net = D.ContextUnet(3, F, 4, bottleneck_k=k, dtype=dtype)
+    net.load_state_dict({kk: synth.synth_tensor(kk, tuple(s)) for kk, s in SCHEMA[tag]}, strict=True)
+    return net.to(DEV)
+
+
+def grad_table(hip_vecs, ref_vecs, skip=("local_enhance",)):
+    """Per child: norm ratio error |hip|/|ref| - 1 and 1 - cosine."""
+    t = {}
+    for cn, r in ref_vecs.items():
+        if cn in skip or np.linalg.norm(r) == 0:
+            continue
+        h = hip_vecs[cn]
+        t[cn] = {"norm_rel_err": float(np.linalg.norm(h) / np.linalg.norm(r) - 1.0), "one_minus_cos": float(1.0 - _cos(h, r))}
+    return t
+
+
+def unet_case(dtype, modes=("eval", "train")):
+    """HIP ContextUnet(F=32) at 64x64 on the unet32_64 inputs against the reference's float64 run."""
+    tag = "unet32_64"
+    g, gb = npz(tag), npz("bf16_autocast")
+    x = si(tag + ".x", (2, 3, 64, 64))
+    c, t, mk = torch.tensor(g["c"]), torch.tensor(g["t"]), torch.tensor(g["ctx_mask"])
+    probe = si(tag + ".probe", (2, 3, 64, 64))
+    out = {}
+    for mode in modes:
+        train = mode == "train"
+        net = hip_unet(tag, dtype)
+        net.train(train)
+        eps = net(x.to(DEV), c.to(DEV), t.to(DEV), mk.to(DEV))
+        loss = (eps * probe.to(DEV)).mean()
+        loss.backward()
+        e = eps.detach().cpu().double().numpy()
+        e64 = gb[f"unet.{mode}.eps64"]
+        # float64 oracle gradients (the oracle equals the reference in float64 to 3e-13, tests/test_oracle_golden.py)
+        P = synth_state(tag, torch.float64)
+        eo = O.context_unet(P, x.double(), c, t.double(), mk.double(), train)
+        (eo * probe.double()).mean().backward()
+        ref_vecs = oracle_child_vectors(P, _names_by_child(net))
+        out[mode] = {
+            "eps_mse_vs_ref64": float(((e - e64) ** 2).mean()), "eps_maxabs_vs_ref64": float(np.abs(e - e64).max()),
+            "signal_power": float((e64 ** 2).mean()),
+            "ref_autocast_bf16_mse": float(gb[f"unet.{mode}.mse_bf16_vs_64"]), "ref_autocast_bf16_maxabs": float(gb[f"unet.{mode}.maxabs_bf16_vs_64"]),
+            "loss": float(loss.item()), "loss_ref64": float(gb[f"unet.{mode}.loss64"]), "loss_ref_autocast_bf16": float(gb[f"unet.{mode}.loss_bf16"]),
+            "grads": grad_table(child_grad_vectors(net), ref_vecs),
+            "ref_autocast_bf16_grads": {cn: {"norm_rel_err": float(gb[f"unet.{mode}.gn_bf16.{cn}"] / gb[f"unet.{mode}.gn64.{cn}"] - 1.0),
+                                             "one_minus_cos": float(1.0 - gb[f"unet.{mode}.cos_bf16.{cn}"])}
+                                        for cn in ref_vecs if cn != "local_enhance" and float(gb[f"unet.{mode}.gn64.{cn}"]) > 0},
+        }
+    return out
+
+
+def ddpm_case(dtype):
+    """HIP DDPM.forward on the ddpm_fwd64 case (draws injected) against the reference's float64 run."""
+    import diffusionmodel_amd as D
+    tag, B, S, n_T = "ddpm_fwd64", 4, 64, 1000
+    g, gb = npz(tag), npz("bf16_autocast")
+    x = si(tag + ".x", (B, 3, S, S))
+    c = torch.tensor([(i + 2) % 4 for i in range(B)])
+    am = synth.synth_attn_mask(B, S)
+    ts, keep = torch.tensor(g["ts"]), torch.tensor(g["keep"])
+    noise = synth.synth_noise(tag + ".noise", (B, 3, S, S))
+    out = {}
+    for mode in ("train", "eval"):
+        ddpm = D.DDPM(D.ContextUnet(3, 32, 4, bottleneck_k=4, dtype=dtype), (1e-4, 0.02), n_T, DEV, drop_prob=0.1)
+        sd = {k: synth.synth_tensor(k, tuple(s)) for k, s in SCHEMA[tag]}
+        for k in D.SCHEDULE_KEYS:
+            sd[k] = D.ddpm_schedules(1e-4, 0.02, n_T)[k]
+        ddpm.load_state_dict(sd)
+        ddpm.train(mode == "train")
+        loss = ddpm(x.to(DEV), c.to(DEV), am.to(DEV), ts=ts.to(DEV), noise=noise.to(DEV), ctx_mask=keep.to(DEV))
+        rec = {"loss": float(loss.item()), "loss_ref64": float(gb[f"ddpm.{mode}.loss64"]), "loss_ref_autocast_bf16": float(gb[f"ddpm.{mode}.loss_bf16"])}
+        if mode == "train":
+            loss.backward()
+            P = synth_state(tag, torch.float64)
+            sched = {k: v.double() for k, v in O.ddpm_schedules(1e-4, 0.02, n_T).items()}
+            lo = O.ddpm_loss(P, sched, n_T, x.double(), c, am.double(), ts, noise.double(), keep.double(), True)
+            lo.backward()
+            rec["loss_oracle64"] = float(lo.item())
+            ref_vecs = oracle_child_vectors(P, _names_by_child(ddpm.nn_model, "nn_model."))
+            rec["grads"] = grad_table(child_grad_vectors(ddpm.nn_model), ref_vecs)
+            rec["ref_autocast_bf16_grads"] = {cn: {"norm_rel_err": float(gb[f"ddpm.train.gn_bf16.{cn}"] / gb[f"ddpm.train.gn64.{cn}"] - 1.0),
+                                                   "one_minus_cos": float(1.0 - gb[f"ddpm.train.cos_bf16.{cn}"])}
+                                              for cn in ref_vecs if cn != "local_enhance" and float(gb[f"ddpm.train.gn64.{cn}"]) > 0}
+        out[mode] = rec
+    return out
+
+
+def f128_case(B=8, S=64, F=128):
+    """The benchmark's width (F=128, 64x64, k=4) at B=8 in bf16 against the float32 oracle on the same seeded weights and
+    inputs; the reference's autocast run does not exist for this size (no fixture), so the yardstick is the oracle itself run
+    under torch.autocast("cpu", bfloat16) — same ops as the reference under autocast."""
+    import diffusionmodel_amd as D
+    torch.manual_seed(1234)
+    net = D.ContextUnet(3, F, 4, bottleneck_k=4, dtype=torch.bfloat16)
+    with torch.no_grad():                                     # non-trivial BatchNorm state so that eval mode is not the identity
+        for n_, b in net.named_buffers():
+            if n_.endswith("running_mean"):
+                b.normal_(0, 0.1)
+            elif n_.endswith("running_var"):
+                b.uniform_(0.6, 1.4)
+    sd = {k: v.detach().clone().cpu() for k, v in net.state_dict().items()}
+    net = net.to(DEV)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 3, S, S, generator=g).clamp_(-1, 1)
+    c = torch.randint(0, 4, (B,), generator=g)
+    t = torch.rand(B, generator=g)
+    mk = (torch.rand(B, generator=g) > 0.2).float()
+    probe = torch.randn(B, 3, S, S, generator=g)
+    out = {}
+    for mode in ("eval", "train"):
+        train = mode == "train"
+        net.load_state_dict(sd)
+        net.train(train)
+        eps = net(x.to(DEV), c.to(DEV), t.to(DEV), mk.to(DEV))
+        loss = (eps * probe.to(DEV)).mean()
+        loss.backward()
+        hip_vecs = child_grad_vectors(net)
+        net.zero_grad()
+        e = eps.detach().cpu().double().numpy()
+        P = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v.clone()) for k, v in sd.items()}
+        eo = O.context_unet(P, x, c, t, mk, train)
+        lo = (eo * probe).mean()
+        lo.backward()
+        ref_vecs = oracle_child_vectors(P, _names_by_child(net))
+        e32 = eo.detach().double().numpy()
+        P16 = {k: v.detach().clone() for k, v in sd.items()}
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            e16 = O.context_unet(P16, x, c, t, mk, train).float().double().numpy()
+        out[mode] = {"eps_mse_vs_oracle32": float(((e - e32) ** 2).mean()), "eps_maxabs_vs_oracle32": float(np.abs(e - e32).max()),
+                     "signal_power": float((e32 ** 2).mean()),
+                     "oracle_autocast_bf16_mse": float(((e16 - e32) ** 2).mean()), "oracle_autocast_bf16_maxabs": float(np.abs(e16 - e32).max()),
+                     "loss": float(loss.item()), "loss_oracle32": float(lo.item()),
+                     "grads": grad_table(hip_vecs, ref_vecs)}
+    return out
+
+
+def train3_case(dtype):
+    """Three optimiser steps (accumulation 2, clip 1.0, AdamW lr 1e-3 wd 1e-2) through the product path — DDPM.forward / ACCUM,
+    backward, FusedAdamW.step — on the draws of tests/golden/train3.npz (the reference's loop on the CPU, fp32)."""
+    import diffusionmodel_amd as D
+    g = npz("train3")
+    lr, wd, accum, n_opt, B = [float(v) for v in g["hyper"]]
+    accum, n_opt, B = int(accum), int(n_opt), int(B)
+    S, n_T = 64, 1000
+    ddpm = D.DDPM(D.ContextUnet(3, 32, 4, bottleneck_k=4, dtype=dtype), (1e-4, 0.02), n_T, DEV, drop_prob=0.1)
+    sd = {k: synth.synth_tensor(k, tuple(s)) for k, s in SCHEMA["ddpm_fwd64"]}
+    for k in D.SCHEDULE_KEYS:
+        sd[k] = D.ddpm_schedules(1e-4, 0.02, n_T)[k]
+    ddpm.load_state_dict(sd)
+    ddpm.train()
+    opt = D.FusedAdamW(ddpm.parameters(), lr=lr, weight_decay=wd, max_grad_norm=1.0)
+    losses, norms = [], []
+    opt.zero_grad()
+    for m in range(accum * n_opt):
+        tag = f"train3.m{m}"
+        x = si(tag + ".x", (B, 3, S, S)).to(DEV)
+        c = torch.tensor([(m + i) % 4 for i in range(B)]).to(DEV)
+        am = synth.synth_attn_mask(B, S).to(DEV)
+        noise = synth.synth_noise(tag + ".noise", (B, 3, S, S)).to(DEV)
+        loss = ddpm(x, c, am, ts=torch.tensor(g[f"ts.{m}"]).to(DEV), noise=noise, ctx_mask=torch.tensor(g[f"keep.{m}"]).to(DEV)) / accum
+        losses.append(float(loss.item()) * accum)
+        loss.backward()
+        if (m + 1) % accum == 0:
+            opt.step()
+            norms.append(float(opt.grad_norm().item()))
+            opt.zero_grad()
+    named = dict(ddpm.named_parameters())
+    rec = {"losses": losses, "losses_ref": [float(v) for v in g["losses"]], "grad_norms": norms, "grad_norms_ref": [float(v) for v in g["grad_norms"]]}
+    rec["loss_rel_err"] = [abs(a - b) / abs(b) for a, b in zip(losses, rec["losses_ref"])]
+    rec["grad_norm_rel_err"] = [abs(a - b) / abs(b) for a, b in zip(norms, rec["grad_norms_ref"])]
+    pn_err = {}
+    for cn, ch in ddpm.nn_model.named_children():
+        ps = [p.detach().double().reshape(-1) for p in ch.parameters()]
+        if ps and f"pnorm.{cn}" in g.files:
+            pn_err[cn] = float(torch.cat(ps).norm().item() / float(g[f"pnorm.{cn}"]) - 1.0)
+    rec["param_norm_rel_err"] = pn_err
+    osd = opt.state_dict()
+    idx = {n: i for i, (n, _) in enumerate(ddpm.named_parameters())}
+    tens = {}
+    for key in g.files:
+        if key.startswith("p."):
+            pn = key[2:]
+            ref_p, ref_m, ref_v = g[key], g["m." + pn], g["v." + pn]
+            st = osd["state"][idx[pn]]
+            tens[pn] = {"param_maxabs_err": float(np.abs(named[pn].detach().cpu().numpy() - ref_p).max()),
+                        "param_update_scale": lr * n_opt,
+                        "exp_avg_rel_err": float(np.abs(st["exp_avg"].cpu().numpy() - ref_m).max() / (np.abs(ref_m).max() + 1e-30)),
+                        "exp_avg_sq_rel_err": float(np.abs(st["exp_avg_sq"].cpu().numpy() - ref_v).max() / (np.abs(ref_v).max() + 1e-30)),
+                        "step": float(st["step"]), "step_ref": float(g["step." + pn])}
+    rec["tensors"] = tens
+    sd2 = ddpm.state_dict()
+    rec["bn_buffers_rel_err"] = {k[4:]: float(np.abs(sd2[k[4:]].cpu().numpy() - g[k]).max() / (np.abs(g[k]).max() + 1e-30)) for k in g.files if k.startswith("buf.")}
+    rec["num_batches_tracked"] = [int(sd2["nn_model.init_conv.conv1.1.num_batches_tracked"]), int(g["nbt"])]
+    return rec
+
+
+def bn_bwd_kernel_case():
+    """conv3x3 + train-mode BatchNorm + GELU (one ConvBnAct node, halo kernel + BN kernels) in bf16 against torch fp32 on the CPU,
+    next to the same torch modules run under autocast(bfloat16): the kernel-level yardstick for test_gpu_kernels."""
+    import torch.nn.functional as F
+    from diffusionmodel_amd import ops as o
+    torch.manual_seed(0)
+    B, Ci, Co, H = 2, 64, 128, 32
+    x = torch.randn(B, Ci, H, H).bfloat16().float()
+    conv_r = torch.nn.Conv2d(Ci, Co, 3, 1, 1)
+    with torch.no_grad():
+        conv_r.weight.copy_(conv_r.weight.bfloat16().float())
+    bn_r = torch.nn.BatchNorm2d(Co)
+    with torch.no_grad():
+        bn_r.weight.uniform_(0.5, 1.5)
+        bn_r.bias.uniform_(-0.3, 0.3)
+    st = {k: v.clone() for k, v in bn_r.state_dict().items()}
+    probe = torch.randn(B, Co, H, H)
+
+    def torch_run(autocast):
+        bn_r.load_state_dict(st)
+        xr = x.clone().requires_grad_(True)
+        conv_r.zero_grad(); bn_r.zero_grad()
+        if autocast:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                y = F.gelu(bn_r(conv_r(xr)))
+        else:
+            y = F.gelu(bn_r(conv_r(xr)))
+        (y.float() * probe).sum().backward()
+        return y.detach().float(), xr.grad.clone(), conv_r.weight.grad.clone(), bn_r.weight.grad.clone(), bn_r.bias.grad.clone()
+    ref = torch_run(False)
+    a16 = torch_run(True)
+
+    class Holder:
+        def __init__(s, w, b):
+            s.weight = torch.nn.Parameter(w.to(DEV).contiguous(memory_format=torch.channels_last))
+            s.bias = torch.nn.Parameter(b.to(DEV))
+    bn_d = torch.nn.BatchNorm2d(Co).to(DEV)
+    bn_d.load_state_dict(st)
+    conv_d = Holder(conv_r.weight.detach().clone(), conv_r.bias.detach().clone())
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV).bfloat16().requires_grad_(True)
+    y = o.conv_bn_act(xd, None, conv_d, bn_d, o.ConvSpec(3, 3, 1, 1, o.ACT_GELU, bn_d))
+    (y.float() * probe.permute(0, 2, 3, 1).contiguous().to(DEV)).sum().backward()
+    hip = (y.detach().float().permute(0, 3, 1, 2).cpu(), xd.grad.float().permute(0, 3, 1, 2).cpu(), conv_d.weight.grad.cpu(),
+           bn_d.weight.grad.cpu(), bn_d.bias.grad.cpu())
+
+    def rel(a, b):
+        return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+
+    def rms(a, b):
+        return float(((a.double() - b.double()) ** 2).mean().sqrt() / (b.double() ** 2).mean().sqrt())
+    names = ("y", "dx", "dw", "dgamma", "dbeta")
+    return {n: {"hip_maxrel": rel(h, r), "torch_autocast_maxrel": rel(a, r), "hip_rms_rel": rms(h, r), "torch_autocast_rms_rel": rms(a, r)}
+            for n, h, a, r in zip(names, hip, a16, ref)}
+
+
+def measure_all():
+    out = {"unet32_64": {"bf16": unet_case(torch.bfloat16), "fp32": unet_case(torch.float32)},
+           "ddpm_fwd64": {"bf16": ddpm_case(torch.bfloat16), "fp32": ddpm_case(torch.float32)},
+           "f128_b8_bf16_vs_oracle_fp32": f128_case(),
+           "train3": {"fp32": train3_case(torch.float32), "bf16": train3_case(torch.bfloat16)},
+           "conv_bn_gelu_kernel_bf16": bn_bwd_kernel_case()}
+    return out

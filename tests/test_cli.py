@@ -12,13 +12,14 @@ sys.path.insert(0, ROOT)
 def test_cli_accepts_both_flag_spellings(monkeypatch):
     import new_scripy as ns
     calls = {}
-    monkeypatch.setattr(ns, "gen_samples", lambda ckpt, n, scales: calls.update(ckpt=ckpt, n=n, scales=scales))
+    monkeypatch.setattr(ns, "gen_samples", lambda ckpt, n_samples_per_class, guide_scales, eval_quality, data_root:
+                        calls.update(ckpt=ckpt, n=n_samples_per_class, scales=guide_scales, ev=eval_quality))
     monkeypatch.setattr(ns, "train_model", lambda max_epochs=None, data_root=None: calls.update(train=max_epochs))
     ns.main(["--mode", "generate", "--ckpt", "a.pt", "--guide_scales", "2", "4", "--samples", "5", "--no_eval"])
-    assert calls == {"ckpt": "a.pt", "n": 5, "scales": [2.0, 4.0]}
+    assert calls == {"ckpt": "a.pt", "n": 5, "scales": [2.0, 4.0], "ev": False}
     calls.clear()
     ns.main(["--mode", "generate", "--checkpoint", "b.pt", "--guidance_scales", "6", "--samples_per_class", "2", "--no_memory_cleanup"])
-    assert calls == {"ckpt": "b.pt", "n": 2, "scales": [6.0]}
+    assert calls == {"ckpt": "b.pt", "n": 2, "scales": [6.0], "ev": True}
     calls.clear()
     ns.main(["--mode", "train", "--epochs", "3"])
     assert calls == {"train": 3}
@@ -27,15 +28,41 @@ def test_cli_accepts_both_flag_spellings(monkeypatch):
 
 
 def test_early_stop_patience():
+    """new_scripy.py:587-620: the call returns "improved" (the caller writes best_model.pt), `.early_stop` flips after `patience`
+    epochs without an improvement of at least min_delta, best_state is the 3-key dict of best_model_early.pt."""
     import new_scripy as ns
-    es = ns.EarlyStop(patience=2, min_delta=0.1)
-    assert not es(1.0, None, 0)
-    assert not es(0.95, None, 1)      # not better by min_delta -> counter 1
-    assert es(0.96, None, 2)          # counter 2 -> stop
-    es = ns.EarlyStop(patience=2, min_delta=0.1)
+    es = ns.EarlyStop(patience=2, min_delta=0.1, verbose=False)
+    assert es(1.0, None, 0) is True and es.best_state["epoch"] == 0 and set(es.best_state) == {"epoch", "model_state_dict", "val_loss"}
+    assert es(0.95, None, 1) is False and es.counter == 1 and not es.early_stop      # not better by min_delta
+    assert es(0.96, None, 2) is False and es.early_stop                              # counter 2 -> stop
+    es = ns.EarlyStop(patience=2, min_delta=0.1, verbose=False)
     es(1.0, None, 0)
-    es(0.8, None, 1)
-    assert es.counter == 0 and es.best_loss == 0.8
+    assert es(0.8, None, 1) is True
+    assert es.counter == 0 and es.best_loss == 0.8 and es.best_state["val_loss"] == 0.8
+
+
+def test_grid_and_image_writers(tmp_path):
+    """save_samples = make_grid(nrow, padding=2) + save_image; save_image quantises like torchvision (x*255+0.5)."""
+    import numpy as np
+    from PIL import Image
+    import new_scripy as ns
+    x = torch.linspace(-1, 1, 6 * 3 * 4 * 5).reshape(6, 3, 4, 5)
+    ns.save_samples(x, str(tmp_path / "g.png"), nrow=4)
+    g = np.array(Image.open(tmp_path / "g.png"))
+    assert g.shape == (2 * (4 + 2) + 2, 4 * (5 + 2) + 2, 3)                # 2 rows of 4 with 2-pixel padding
+    assert (g[:2] == 0).all() and (g[:, :2] == 0).all()
+    want = ((x[5] * 0.5 + 0.5).clamp(0, 1) * 255 + 0.5).to(torch.uint8).permute(1, 2, 0).numpy()
+    assert (g[2 + 6:2 + 6 + 4, 2 + 7:2 + 7 + 5] == want).all()             # image 5 sits in row 1, column 1
+    ns.save_image(x[0], str(tmp_path / "i.png"))
+    assert np.array(Image.open(tmp_path / "i.png")).shape == (4, 5, 3)
+
+
+def test_generate_infers_class_count_from_checkpoint():
+    import new_scripy as ns
+    assert ns._classes_of_checkpoint({"nn_model.ctx_emb1.model.0.weight": torch.zeros(256, 5)}) == 5
+    assert ns._classes_of_checkpoint({"ctx_emb1.model.0.weight": torch.zeros(256, 7)}) == 7
+    with pytest.raises(KeyError):
+        ns._classes_of_checkpoint({"foo": torch.zeros(1)})
 
 
 @pytest.mark.gpu
@@ -48,15 +75,44 @@ def test_train_then_generate_synthetic(tmp_path, monkeypatch):
     try:
         Cfg.IMG_SIZE, Cfg.N_FEAT, Cfg.N_T, Cfg.BATCH_SIZE, Cfg.ACCUM_STEPS, Cfg.BOTTLENECK_K = 64, 32, 8, 4, 2, 4
         Cfg.SAVE_DIR, Cfg.SAMPLE_DIR, Cfg.GUIDE_SCALES = str(tmp_path / "ckpt") + "/", str(tmp_path / "samples") + "/", [2.0]
-        ddpm, hist = ns.train_model(n_classes=4, n_train=16, n_val=8, max_epochs=2, quiet=True)
+        ddpm, hist = ns.train_model(n_classes=4, n_train=18, n_val=8, max_epochs=2, quiet=True)       # 18 = 4 full batches + a tail of 2
         assert len(hist) == 2 and all(torch.isfinite(torch.tensor(h["train_loss"])) for h in hist)
         ck = os.path.join(Cfg.SAVE_DIR, "ckpt_ep1.pt")
         assert os.path.isfile(ck)
         sd = torch.load(ck, map_location="cpu", weights_only=True)
         assert set(sd) == {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "loss", "metrics"}
-        out = ns.gen_samples(ck, n_samples_per_class=1, guide_scales=[2.0], n_classes=4)
-        assert out[2.0].shape == (4, 3, 64, 64) and torch.isfinite(out[2.0]).all()
-        assert os.path.isfile(os.path.join(Cfg.SAMPLE_DIR, "generated_w2.0.png"))
+        # the optimiser state is torch.optim.AdamW's schema (new_scripy.py:736-743 saves optim.state_dict())
+        osd = sd["optimizer_state_dict"]
+        n_par = len(list(ddpm.parameters()))
+        assert osd["param_groups"][0]["params"] == list(range(n_par)) and len(osd["state"]) == n_par
+        assert set(osd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+        # 5 micro-batches per epoch with ACCUM_STEPS = 2 -> 3 optimiser steps per epoch (the tail group is flushed, :795)
+        assert float(osd["state"][0]["step"]) == 6.0
+        assert set(sd["metrics"]) == {"train_loss", "val_loss", "img_metrics", "lr"} and len(sd["metrics"]["train_loss"]) == 2
+        best = torch.load(os.path.join(Cfg.SAVE_DIR, "best_model.pt"), map_location="cpu", weights_only=True)
+        assert set(best) == set(sd)                                                   # the 6-key dict (:898-901)
+        assert os.path.isfile(os.path.join(Cfg.SAVE_DIR, "metrics", "metrics_ep1.json"))
+        assert os.path.isfile(os.path.join(Cfg.SAVE_DIR, "img_ep0_w2.0.png"))         # periodic sampling at ep % 5 == 0 (:851)
+        assert sd["metrics"]["img_metrics"] and {"ssim", "psnr", "guide_scale", "epoch"} <= set(sd["metrics"]["img_metrics"][0])
+        real = torch.rand(4, 3, 64, 64) * 2 - 1
+        out = ns.gen_samples(ck, n_samples_per_class=1, guide_scales=[2.0], real_images=real)          # class count from the checkpoint
+        x = out[2.0]["samples"]
+        assert x.shape == (4, 3, 64, 64) and torch.isfinite(x).all()
+        d = os.path.dirname(out[2.0]["grid_path"])
+        assert os.path.isfile(out[2.0]["grid_path"]) and os.path.basename(out[2.0]["grid_path"]) == "samples_g2.0.png"
+        assert all(os.path.isfile(os.path.join(d, f"class{i}_s0_g2.0.png")) for i in range(4))
+        assert os.path.isfile(os.path.join(d, "quality_metrics.json"))
+        # resume: a fresh optimiser takes the saved state back (moments, step) in torch's layout
+        import diffusionmodel_amd as D
+        d2 = ns.build_model(4, "cuda:0")
+        d2.load_state_dict(sd["model_state_dict"])
+        o2 = D.FusedAdamW(d2.parameters(), lr=Cfg.LR, weight_decay=Cfg.WD)
+        o2.load_state_dict(osd)
+        assert o2._step == 6 and int(o2._step_dev.item()) == 6
+        back = o2.state_dict()
+        for i in (0, 7, n_par - 1):
+            assert torch.equal(back["state"][i]["exp_avg"].cpu(), osd["state"][i]["exp_avg"])
+            assert torch.equal(back["state"][i]["exp_avg_sq"].cpu(), osd["state"][i]["exp_avg_sq"])
     finally:
         for k, v in saved.items():
             setattr(Cfg, k, v)
