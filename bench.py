@@ -83,6 +83,27 @@ def _cpu_info():
     return model, (len(phys) or None), usable
 
 
+def _cpu_quota():
+    """CPU limit of this container in cores (cgroup v2 cpu.max / v1 cfs quota), or None."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        if q != "max":
+            return max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = int(f.read())
+        if q > 0:
+            return max(1, q // per)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def _timed(fn, n_timed, warm=1):
     for _ in range(warm):
         fn()
@@ -125,15 +146,21 @@ def cpu_baseline(args):
         torch.nn.utils.clip_grad_norm_(params, 1.0)
         opt.step()
 
-    cands = sorted({t for t in (usable, phys or usable, 64, 32) if t and t <= usable}, reverse=True)
-    sweep = {}
-    for t in cands:                                   # 1 warm-up + 1 timed iteration per candidate
+    quota = _cpu_quota()
+    cap = min(usable, quota) if quota else usable
+    cands = sorted({t for t in (cap, min(phys or cap, cap), 64, 32, 16) if t and t <= cap}, reverse=True)
+    sweep, t_begin = {}, time.perf_counter()
+    for i, t in enumerate(cands):                     # 1 warm-up + 1 timed iteration per candidate, inside a time budget
+        if i and time.perf_counter() - t_begin > 60:
+            break
         torch.set_num_threads(t)
         sweep[t] = round(_timed(train_step, 1)[0], 3)
+        print(f"[bench] cpu baseline: {t} threads -> {sweep[t]:.2f} s per B={Bs} train step", file=sys.stderr, flush=True)
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
     n_it = max(3, args.cpu_iters)
     t_train, all_train = _timed(train_step, n_it, warm=0)
+    print(f"[bench] cpu baseline: train leg {t_train:.2f} s/iter at {best} threads", file=sys.stderr, flush=True)
     scale = args.batch / Bs
 
     # (b) cfg-2 sample step: one iteration of DDPM.sample's loop (denoiser on the CFG-doubled batch + update), eval mode
@@ -144,6 +171,7 @@ def cpu_baseline(args):
         with torch.no_grad():
             O.ddpm_sample(P, sched, 1000, 4, xs, zs, 2.0, steps=1)
     t_samp, _ = _timed(sample_step, n_it)
+    print(f"[bench] cpu baseline: sample leg {t_samp:.2f} s/iter", file=sys.stderr, flush=True)
 
     # (c) cfg-1: MNIST_script.py net, 28x28, F=64, T=400, B=64 (train) / n=60 (sample: labels cycle over 10 classes)
     PM = _rand_state(O.mnist_unet_spec(1, 64, 10, 7))
@@ -172,7 +200,7 @@ def cpu_baseline(args):
     t_ms, _ = _timed(mnist_sample, n_it)
 
     return {"value": round(1.0 / (t_train * scale), 5), "unit": "denoiser-steps/s (train, B=%d)" % args.batch, "cores": best,
-            "kind": "port", "cpu_model": model, "physical_cores": phys, "usable_threads": usable,
+            "kind": "port", "cpu_model": model, "physical_cores": phys, "usable_threads": usable, "cgroup_cpu_quota": quota,
             "thread_sweep_s_per_iter": {str(k): v for k, v in sweep.items()},
             "sample": f"oracle train step (fwd+bwd+clip+AdamW) fp32 at B={Bs} x{scale:g} scaled, {n_it} timed iters at {best} threads "
                       f"({', '.join('%.2f' % v for v in all_train)} s)",

@@ -65,6 +65,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._table = None                            # (pinned host, device) pointer table of gather_grads
         self._step_dev = torch.zeros(1, dtype=torch.int64, device=dev)   # step count on the device (bias corrections)
         self._captured_tables = []                    # pointer tables a stream capture baked into a graph: never reused
+        self._capture_spare = None                    # the table the next capture will take (allocated on the eager path)
         self.refresh_shadow()
         ops.bump_weight_epoch()
         # the gradient scratch arena is recycled by step(); that is only sound while ONE optimiser consumes the gradients of
@@ -88,6 +89,10 @@ class FusedAdamW(torch.optim.Optimizer):
         for p, _, _ in self._slots:
             p.grad = None
 
+    def _new_table(self, cap):
+        return [torch.empty((cap, 3), dtype=torch.int64).pin_memory(),
+                torch.empty((cap, 3), dtype=torch.int64, device=self.flat_g.device), None]
+
     def gather_grads(self):
         """Fold autograd-produced `.grad` tensors (everything that is not a main_grad conv weight)
         into the flat gradient buffer with one multi-tensor launch."""
@@ -107,19 +112,24 @@ class FusedAdamW(torch.optim.Optimizer):
         if rows:
             # pointer table: pinned host buffers (so the upload is a plain async copy, legal in a stream capture), a ring of
             # four guarded by events because the host runs ahead of the device in eager mode
-            if self._table is None or self._table[0][0].shape[0] < len(rows):
-                cap = max(2 * len(rows), 1024)
-                self._table = [[torch.empty((cap, 3), dtype=torch.int64).pin_memory(),
-                                torch.empty((cap, 3), dtype=torch.int64, device=self.flat_g.device), None] for _ in range(4)]
-                self._table_i = 0
             capturing = torch.cuda.is_current_stream_capturing()
+            if not capturing and (self._table is None or self._table[0][0].shape[0] < len(rows)):
+                cap = max(2 * len(rows), 1024)
+                self._table = [self._new_table(cap) for _ in range(4)]
+                self._table_i = 0
             if capturing:
                 # the upload becomes a graph node that re-reads its pinned source on every replay: the capture gets a table of its
-                # own (host and device) that lives as long as the optimiser and is never recycled by later eager steps
-                slot = [torch.empty((len(rows), 3), dtype=torch.int64).pin_memory(),
-                        torch.empty((len(rows), 3), dtype=torch.int64, device=self.flat_g.device), None]
+                # own (host and device) that lives as long as the optimiser and is never recycled by later eager steps.  Pinned
+                # memory cannot be allocated inside a capture, so the spare was set aside by the last eager call.
+                slot = self._capture_spare
+                if slot is None or slot[0].shape[0] < len(rows):
+                    raise DmError("FusedAdamW: run one eager step() before capturing it in a graph (the pointer table of the "
+                                  "gradient gather is allocated on the eager path)")
+                self._capture_spare = None
                 self._captured_tables.append(slot)
             else:
+                if self._capture_spare is None or self._capture_spare[0].shape[0] < len(rows):
+                    self._capture_spare = self._new_table(max(2 * len(rows), 1024))
                 slot = self._table[self._table_i]
                 self._table_i = (self._table_i + 1) % 4
                 if slot[2] is not None:

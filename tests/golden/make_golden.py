@@ -278,6 +278,7 @@ def main():
     gen_metrics_and_masks(R)
     gen_bf16_autocast(R)
     gen_train3(R)
+    gen_train3(R, autocast=True)
     # key schema of the full-size nets (shapes only; no tensors are instantiated for the big ones)
     SCHEMA["ddpm_keys_F32_k4"] = [(k, list(v.shape)) for k, v in
                                   R.DDPM(make_ref_unet(R, 32, 4, 4), (1e-4, 0.02), 1000, "cpu").state_dict().items()]
@@ -454,7 +455,7 @@ def gen_bf16_autocast(R, S=64, k=4, nf=32, ncls=4):
     np.savez_compressed(os.path.join(OUT, "bf16_autocast.npz"), **out)
 
 
-def gen_train3(R, S=64, k=4, nf=32, ncls=4, B=2, n_T=1000, accum=2, n_opt=3, lr=1e-3, wd=1e-2):
+def gen_train3(R, S=64, k=4, nf=32, ncls=4, B=2, n_T=1000, accum=2, n_opt=3, lr=1e-4, wd=1e-5, autocast=False):
     """Three optimiser steps of the reference's train loop (new_scripy.py:777-803: loss / ACCUM_STEPS, backward, every ACCUM_STEPS
     micro-batches clip_grad_norm_(1.0) + AdamW.step + zero_grad) on the CPU in fp32, with every random draw injected
     (micro-batch m uses the tags train3.m<m>.*).  Pins the training driver + fused optimiser: per-micro-batch losses, the
@@ -481,7 +482,8 @@ def gen_train3(R, S=64, k=4, nf=32, ncls=4, B=2, n_T=1000, accum=2, n_opt=3, lr=
             ts = torch.tensor([1 + (313 * (i + 2 * m) + 96) % n_T for i in range(B)])
             keep = torch.tensor([float(((i + m) % 3) != 1) for i in range(B)])
             with mock.patch.object(torch, "randint", lambda *a, **kw: ts), mock.patch.object(torch, "randn_like", inj.randn_like), \
-                    mock.patch.object(torch, "bernoulli", lambda p, **kw: keep):
+                    mock.patch.object(torch, "bernoulli", lambda p, **kw: keep), \
+                    torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):             # :784 (bf16 variant: train3_bf16.npz)
                 loss = ddpm(x, c, am) / R.Cfg.ACCUM_STEPS                                   # :785-786
             out["losses"].append(loss.item() * R.Cfg.ACCUM_STEPS)                          # :789
             loss.backward()
@@ -494,6 +496,10 @@ def gen_train3(R, S=64, k=4, nf=32, ncls=4, B=2, n_T=1000, accum=2, n_opt=3, lr=
         R.Cfg.ACCUM_STEPS = old
     res = {"losses": np.array(out["losses"]), "grad_norms": np.array(out["grad_norms"]),
            "hyper": np.array([lr, wd, accum, n_opt, B])}
+    if autocast:       # the reference's own bf16 trajectory: only what the tolerance of the HIP bf16 run is derived from
+        np.savez_compressed(os.path.join(OUT, "train3_bf16.npz"), **res)
+        print("train3 (autocast bf16) losses", res["losses"], "grad norms", res["grad_norms"])
+        return
     for m in range(accum * n_opt):
         res[f"ts.{m}"], res[f"keep.{m}"] = out[f"ts.{m}"], out[f"keep.{m}"]
     for cn, child in ddpm.nn_model.named_children():
@@ -526,6 +532,7 @@ if __name__ == "__main__":
         R_ = _refload.load("new_scripy")
         gen_bf16_autocast(R_)
         gen_train3(R_)
+        gen_train3(R_, autocast=True)
         with open(os.path.join(OUT, "schema.json")) as f:
             full = json.load(f)
         full.update(SCHEMA)

@@ -114,6 +114,7 @@ def unet_case(dtype, modes=("eval", "train")):
             "signal_power": float((e64 ** 2).mean()),
             "ref_autocast_bf16_mse": float(gb[f"unet.{mode}.mse_bf16_vs_64"]), "ref_autocast_bf16_maxabs": float(gb[f"unet.{mode}.maxabs_bf16_vs_64"]),
             "loss": float(loss.item()), "loss_ref64": float(gb[f"unet.{mode}.loss64"]), "loss_ref_autocast_bf16": float(gb[f"unet.{mode}.loss_bf16"]),
+            "probe_power": float((probe ** 2).mean()), "n_elements": int(probe.numel()),
             "grads": grad_table(child_grad_vectors(net), ref_vecs),
             "ref_autocast_bf16_grads": {cn: {"norm_rel_err": float(gb[f"unet.{mode}.gn_bf16.{cn}"] / gb[f"unet.{mode}.gn64.{cn}"] - 1.0),
                                              "one_minus_cos": float(1.0 - gb[f"unet.{mode}.cos_bf16.{cn}"])}
@@ -196,14 +197,19 @@ def f128_case(B=8, S=64, F=128):
         lo.backward()
         ref_vecs = oracle_child_vectors(P, _names_by_child(net))
         e32 = eo.detach().double().numpy()
-        P16 = {k: v.detach().clone() for k, v in sd.items()}
-        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
-            e16 = O.context_unet(P16, x, c, t, mk, train).float().double().numpy()
+        P16 = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v.clone()) for k, v in sd.items()}
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            eo16 = O.context_unet(P16, x, c, t, mk, train)
+            lo16 = (eo16.float() * probe).mean()
+        lo16.backward()
+        e16 = eo16.detach().float().double().numpy()
+        a16_vecs = oracle_child_vectors(P16, _names_by_child(net))
         out[mode] = {"eps_mse_vs_oracle32": float(((e - e32) ** 2).mean()), "eps_maxabs_vs_oracle32": float(np.abs(e - e32).max()),
                      "signal_power": float((e32 ** 2).mean()),
                      "oracle_autocast_bf16_mse": float(((e16 - e32) ** 2).mean()), "oracle_autocast_bf16_maxabs": float(np.abs(e16 - e32).max()),
-                     "loss": float(loss.item()), "loss_oracle32": float(lo.item()),
-                     "grads": grad_table(hip_vecs, ref_vecs)}
+                     "loss": float(loss.item()), "loss_oracle32": float(lo.item()), "loss_oracle_autocast_bf16": float(lo16.item()),
+                     "probe_power": float((probe ** 2).mean()), "n_elements": int(probe.numel()),
+                     "grads": grad_table(hip_vecs, ref_vecs), "oracle_autocast_bf16_grads": grad_table(a16_vecs, ref_vecs)}
     return out
 
 
@@ -239,6 +245,10 @@ def train3_case(dtype):
             opt.zero_grad()
     named = dict(ddpm.named_parameters())
     rec = {"losses": losses, "losses_ref": [float(v) for v in g["losses"]], "grad_norms": norms, "grad_norms_ref": [float(v) for v in g["grad_norms"]]}
+    gb = npz("train3_bf16")                    # the reference's loop under autocast(bfloat16): how far bf16 moves the reference itself
+    rec["losses_ref_autocast_bf16"], rec["grad_norms_ref_autocast_bf16"] = [float(v) for v in gb["losses"]], [float(v) for v in gb["grad_norms"]]
+    rec["ref_autocast_loss_rel_dev"] = [abs(a - b) / abs(b) for a, b in zip(rec["losses_ref_autocast_bf16"], rec["losses_ref"])]
+    rec["ref_autocast_grad_norm_rel_dev"] = [abs(a - b) / abs(b) for a, b in zip(rec["grad_norms_ref_autocast_bf16"], rec["grad_norms_ref"])]
     rec["loss_rel_err"] = [abs(a - b) / abs(b) for a, b in zip(losses, rec["losses_ref"])]
     rec["grad_norm_rel_err"] = [abs(a - b) / abs(b) for a, b in zip(norms, rec["grad_norms_ref"])]
     pn_err = {}
@@ -256,7 +266,7 @@ def train3_case(dtype):
             ref_p, ref_m, ref_v = g[key], g["m." + pn], g["v." + pn]
             st = osd["state"][idx[pn]]
             tens[pn] = {"param_maxabs_err": float(np.abs(named[pn].detach().cpu().numpy() - ref_p).max()),
-                        "param_update_scale": lr * n_opt,
+                        "param_update_scale": lr * n_opt, "param_moved_maxabs": float(np.abs(ref_p - synth.synth_tensor(pn, tuple(ref_p.shape)).numpy()).max()),
                         "exp_avg_rel_err": float(np.abs(st["exp_avg"].cpu().numpy() - ref_m).max() / (np.abs(ref_m).max() + 1e-30)),
                         "exp_avg_sq_rel_err": float(np.abs(st["exp_avg_sq"].cpu().numpy() - ref_v).max() / (np.abs(ref_v).max() + 1e-30)),
                         "step": float(st["step"]), "step_ref": float(g["step." + pn])}

@@ -1,0 +1,124 @@
+"""Parity of the BENCHMARKED mode (bf16) and of the training trajectory, on a real MI355X.
+
+The yardstick is the reference itself: tests/golden/bf16_autocast.npz holds the reference run under
+torch.autocast("cpu", bfloat16) — the precision new_scripy.py:784 trains in — next to the same code in float64, and
+train3.npz / train3_bf16.npz hold three optimiser steps of its train loop (new_scripy.py:777-803) in fp32 and under autocast.
+The HIP bf16 path has to be at least as close to the float64 result as the reference's own bf16 run is (x a stated margin for
+box-to-box atomic ordering); measured values are in profiles/r02_parity.json (scripts/parity_report.py), from which the
+margins below were taken: on every quantity the HIP path came out CLOSER to float64 than the reference's autocast run.
+"""
+import math
+
+import pytest
+import torch
+
+import parity_lib as PL
+
+pytestmark = pytest.mark.gpu
+MARGIN = 1.25        # HIP error <= MARGIN x the reference's own bf16-autocast error (measured ratios: 0.3 .. 0.85)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _projection_noise(mse, probe_power, n):
+    """|sum(d * probe) / n| for an error field d of mean square `mse` uncorrelated with the probe: sqrt(mse * E[probe^2] / n)."""
+    return math.sqrt(mse * probe_power / n)
+
+
+@pytest.fixture(scope="module")
+def unet16():
+    return PL.unet_case(torch.bfloat16)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_bf16_eps_mse_within_the_references_own_bf16_error(unet16, mode):
+    r = unet16[mode]
+    print(f"bf16 {mode}: HIP eps MSE {r['eps_mse_vs_ref64']:.3e} (max {r['eps_maxabs_vs_ref64']:.3e}) vs reference-autocast "
+          f"{r['ref_autocast_bf16_mse']:.3e} (max {r['ref_autocast_bf16_maxabs']:.3e}); signal power {r['signal_power']:.3f}")
+    assert r["eps_mse_vs_ref64"] <= MARGIN * r["ref_autocast_bf16_mse"]          # requested bar was 2x; measured 0.69x (eval) / 0.43x (train)
+    assert r["eps_maxabs_vs_ref64"] <= 1.5 * r["ref_autocast_bf16_maxabs"]
+    # the scalar loss is a random projection of eps: its error is projection noise of an MSE-sized field (3 sigma of the reference's level)
+    assert abs(r["loss"] - r["loss_ref64"]) <= 3 * _projection_noise(r["ref_autocast_bf16_mse"], r["probe_power"], r["n_elements"])
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_bf16_gradients_every_child_norm_and_cosine(unet16, mode):
+    """All 19 top-level children (not one tensor): gradient norm and direction against the float64 reference gradient."""
+    r = unet16[mode]
+    ref = r["ref_autocast_bf16_grads"]
+    worst_ref_norm = max(abs(v["norm_rel_err"]) for v in ref.values())
+    assert set(r["grads"]) == set(ref) and len(ref) == 19
+    for cn, v in r["grads"].items():
+        assert abs(v["norm_rel_err"]) <= worst_ref_norm, (mode, cn, v, worst_ref_norm)      # eval 0.025 vs 0.066, train 0.058 vs 0.088
+        assert v["one_minus_cos"] <= MARGIN * ref[cn]["one_minus_cos"], (mode, cn, v, ref[cn])
+
+
+def test_bf16_ddpm_forward_loss_and_gradients():
+    r = PL.ddpm_case(torch.bfloat16)
+    for mode in ("train", "eval"):
+        rel = abs(r[mode]["loss"] - r[mode]["loss_ref64"]) / abs(r[mode]["loss_ref64"])
+        ref_rel = abs(r[mode]["loss_ref_autocast_bf16"] - r[mode]["loss_ref64"]) / abs(r[mode]["loss_ref64"])
+        print(f"bf16 DDPM.forward {mode}: loss {r[mode]['loss']:.6f} vs float64 {r[mode]['loss_ref64']:.6f} (rel {rel:.2e}; reference-autocast {ref_rel:.2e})")
+        assert rel <= 2e-3                     # stated relative bar (measured 5.7e-4 / 6.4e-4; the reference's own autocast run: 1.8e-3 / 6.7e-4)
+    g, ref = r["train"]["grads"], r["train"]["ref_autocast_bf16_grads"]
+    worst_ref_norm = max(abs(v["norm_rel_err"]) for v in ref.values())
+    for cn, v in g.items():
+        assert abs(v["norm_rel_err"]) <= worst_ref_norm, (cn, v)                             # 0.107 (ca4) vs 0.34
+        assert v["one_minus_cos"] <= MARGIN * ref[cn]["one_minus_cos"], (cn, v, ref[cn])
+
+
+def test_bf16_benchmark_width_f128_b8_against_fp32_oracle():
+    """F=128 (the benchmark's width), B=8, 64x64: eps MSE, loss and per-child gradients of the HIP bf16 path against the fp32
+    oracle; yardstick = the oracle under autocast(bfloat16) on the same weights (no reference fixture exists at this size)."""
+    r = PL.f128_case()
+    for mode in ("eval", "train"):
+        m = r[mode]
+        print(f"F=128 B=8 bf16 {mode}: eps MSE {m['eps_mse_vs_oracle32']:.3e} vs oracle-autocast {m['oracle_autocast_bf16_mse']:.3e} "
+              f"(signal power {m['signal_power']:.3f}); loss {m['loss']:.3e} vs {m['loss_oracle32']:.3e}")
+        assert m["eps_mse_vs_oracle32"] <= MARGIN * m["oracle_autocast_bf16_mse"]            # measured 0.78x / 0.74x
+        assert m["eps_mse_vs_oracle32"] <= (1e-4 if mode == "eval" else 2e-2) * m["signal_power"]
+        assert abs(m["loss"] - m["loss_oracle32"]) <= 3 * _projection_noise(m["oracle_autocast_bf16_mse"], m["probe_power"], m["n_elements"])
+        ref = m["oracle_autocast_bf16_grads"]
+        worst_norm = max(abs(v["norm_rel_err"]) for v in ref.values())
+        worst_cos = max(v["one_minus_cos"] for v in ref.values())
+        for cn, v in m["grads"].items():
+            assert abs(v["norm_rel_err"]) <= max(worst_norm, 0.05), (mode, cn, v)
+            assert v["one_minus_cos"] <= MARGIN * max(ref[cn]["one_minus_cos"], 0.1 * worst_cos), (mode, cn, v, ref[cn])
+
+
+def test_three_optimiser_steps_reproduce_the_reference_loop_fp32():
+    """new_scripy.py:777-803 on the CPU (torch AdamW + clip_grad_norm_, accumulation 2, the reference's LR / WD) vs the product path
+    (DDPM.forward / ACCUM -> backward -> FusedAdamW.step) in fp32 on the same injected draws."""
+    r = PL.train3_case(torch.float32)
+    print("fp32 train3 losses", r["losses"], "ref", r["losses_ref"], "grad norms", r["grad_norms"], "ref", r["grad_norms_ref"])
+    assert max(r["loss_rel_err"]) <= 2e-4                                                   # micro-batch losses, 6 of them
+    assert max(r["grad_norm_rel_err"]) <= 5e-3                                               # pre-clip global norm of each step
+    assert max(abs(v) for v in r["param_norm_rel_err"].values()) <= 2e-5                    # per-child parameter norms after step 3
+    assert r["num_batches_tracked"][0] == r["num_batches_tracked"][1] == 6
+    assert max(r["bn_buffers_rel_err"].values()) <= 5e-3
+    t = r["tensors"]["nn_model.out.3.weight"]                                                # a well-conditioned tensor, in full
+    assert t["step"] == t["step_ref"] == 3.0
+    assert t["param_maxabs_err"] <= 0.1 * t["param_moved_maxabs"], t                         # the update itself is reproduced, not just the start value
+    assert t["exp_avg_rel_err"] <= 2e-2 and t["exp_avg_sq_rel_err"] <= 3e-2, t
+    for pn, t in r["tensors"].items():                                                      # moments in torch's state_dict() layout
+        assert t["step"] == 3.0 and math.isfinite(t["exp_avg_rel_err"]), pn
+
+
+def test_three_optimiser_steps_bf16_tracks_fp32_and_the_references_bf16_run():
+    """train_sanity as a test: the bf16 loss trajectory stays inside the band the reference's own autocast run spans around
+    its fp32 run (x2), the first step's gradient norm (before any bf16-induced weight difference) inside that run's deviation."""
+    r = PL.train3_case(torch.bfloat16)
+    f = PL.train3_case(torch.float32)
+    print("bf16 train3 losses", r["losses"], "fp32-HIP", f["losses"], "ref fp32", r["losses_ref"], "ref autocast", r["losses_ref_autocast_bf16"])
+    print("bf16 train3 grad norms", r["grad_norms"], "ref fp32", r["grad_norms_ref"], "ref autocast", r["grad_norms_ref_autocast_bf16"])
+    band = 2 * max(r["ref_autocast_loss_rel_dev"]) + 1e-3
+    for a, b, c in zip(r["losses"], r["losses_ref"], f["losses"]):
+        assert abs(a - b) / b <= band and abs(a - c) / c <= band, (a, b, c, band)
+    assert r["grad_norm_rel_err"][0] <= max(r["ref_autocast_grad_norm_rel_dev"][0], 5e-3)
+    assert max(r["grad_norm_rel_err"]) <= 2 * max(r["ref_autocast_grad_norm_rel_dev"]) + 0.02
+    assert max(abs(v) for v in r["param_norm_rel_err"].values()) <= 1e-4
+    assert all(math.isfinite(v) for v in r["losses"])

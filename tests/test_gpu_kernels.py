@@ -166,6 +166,7 @@ def test_conv_halo_kernel_exact_integers(case, halo_variant):
 def test_conv_halo_kernel_bn_statistics(halo_variant):
     """Train-mode BatchNorm behind the halo kernel: the two 128-row statistics partials a 256-pixel tile emits."""
     o = ops()
+    torch.manual_seed(0)
     B, Ci, Co, H = 2, 64, 128, 32
     x = torch.randn(B, Ci, H, H).bfloat16().float()
     conv_r = torch.nn.Conv2d(Ci, Co, 3, 1, 1)
@@ -183,12 +184,17 @@ def test_conv_halo_kernel_bn_statistics(halo_variant):
     spec = o.ConvSpec(3, 3, 1, 1, o.ACT_GELU, bn_d)
     xd = nhwc(x, torch.bfloat16).requires_grad_(True)
     y = o.conv_bn_act(xd, None, conv_d, bn_d, spec)
-    assert rel_err(nchw(y), yr.detach()) < 4e-2
+    # bars from profiles/r02_parity.json ("conv_bn_gelu_kernel_bf16": this very case): HIP bf16 max-rel error y 4.5e-3, dx 3.5e-3,
+    # dw 2.3e-3, dgamma 3.0e-3, dbeta 2.5e-3 — each at or below torch's own autocast(bfloat16) run of the same modules (4.5e-3,
+    # 4.7e-3, 3.8e-3, 3.6e-3, 3.6e-3); the bars are 2x torch-autocast's error
+    assert rel_err(nchw(y), yr.detach()) < 9e-3
     assert rel_err(bn_d.running_mean.cpu(), bn_r.running_mean) < 1e-2
     assert rel_err(bn_d.running_var.cpu(), bn_r.running_var) < 1e-2
     (y.float() * nhwc(probe)).sum().backward()
-    assert rel_err(nchw(xd.grad), xr.grad) < 0.16
-    assert rel_err(conv_d.weight.grad.cpu(), conv_r.weight.grad) < 0.16
+    assert rel_err(nchw(xd.grad), xr.grad) < 9e-3
+    assert rel_err(conv_d.weight.grad.cpu(), conv_r.weight.grad) < 8e-3
+    assert rel_err(bn_d.weight.grad.cpu(), bn_r.weight.grad) < 8e-3
+    assert rel_err(bn_d.bias.grad.cpu(), bn_r.bias.grad) < 8e-3
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -14,6 +14,7 @@ from diffusionmodel_amd import mnist as DM
 from diffusionmodel_amd import parallel
 
 G = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCHEMA = json.load(open(os.path.join(G, "schema.json")))
 
 
@@ -270,3 +271,61 @@ def test_gloo_sharded_sampling_gathers_in_rank_order(tmp_path):
         assert torch.equal(full, want)
         assert torch.equal(local, want[r * 4:(r + 1) * 4])
 
+
+
+# ---- bench.py --gpus N outside torchrun: the parent starts its own ranks and relays rank 0's JSON line -------------------
+def test_bench_self_launcher_starts_ranks_and_relays_one_json_line():
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-selftest"], capture_output=True, text=True,
+                       timeout=300, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["ranks"] == 2 and out["n_gpus"] == 2 and out["sum"] == 2.0 and out["devices"] == ["cpu:0", "cpu:1"]
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode != 0 and "HIP device(s) are visible" in r.stderr
+
+
+# ---- two ranks on one device: the <= 64-KiB-LDS kernel variants are selected, loudly -------------------------------------
+def _guard_worker(rank, world, port, out_dir, same):
+    import torch.distributed as dist
+    from diffusionmodel_amd import parallel
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ident = ("host", "gpu0") if same else ("host", f"gpu{rank}")
+    shared = parallel.guard_shared_device(0, identity=ident)
+    with open(os.path.join(out_dir, f"guard_{int(same)}_{rank}.txt"), "w") as f:
+        f.write(f"{int(shared)} {int(parallel.SHARED_DEVICE[0])}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("same", [True, False])
+def test_gloo_shared_device_guard(tmp_path, same):
+    import torch.multiprocessing as mp
+    port = 31000 + os.getpid() % 2000 + int(same)
+    mp.spawn(_guard_worker, args=(2, port, str(tmp_path), same), nprocs=2, join=True)
+    for rank in range(2):
+        got = open(os.path.join(str(tmp_path), f"guard_{int(same)}_{rank}.txt")).read().split()
+        assert got == ([ "1", "1"] if same else ["0", "0"])
+
+
+def test_adamw_state_dict_schema_fixture_matches_torch():
+    """tests/golden/schema.json["adamw_state_dict"] (written next to train3.npz from the reference's torch.optim.AdamW) is the layout
+    FusedAdamW.state_dict() reproduces (GPU test in test_cli.py); here: the fixture itself agrees with this image's torch."""
+    import json
+    sch = json.load(open(os.path.join(ROOT, "tests", "golden", "schema.json")))["adamw_state_dict"]
+    p = torch.nn.Parameter(torch.zeros(3))
+    o = torch.optim.AdamW([p], lr=1e-4, weight_decay=1e-5)
+    p.grad = torch.ones(3)
+    o.step()
+    sd = o.state_dict()
+    assert sorted(sd["param_groups"][0].keys()) == sch["param_group_keys"]
+    assert sorted(sd["state"][0].keys()) == sch["state_keys"] and str(sd["state"][0]["step"].dtype) == sch["state0"]["step"][1]
+    from diffusionmodel_amd.optim import FusedAdamW
+    assert set(FusedAdamW._GROUP_DEFAULTS) | {"lr", "betas", "eps", "weight_decay", "params"} == set(sch["param_group_keys"])
