@@ -274,10 +274,11 @@ def main():
     ap.add_argument("--cpu-iters", dest="cpu_iters", type=int, default=3)
     ap.add_argument("--launch-selftest", dest="launch_selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--buckets", type=int, default=6)
-    ap.add_argument("--graph", dest="graph", action="store_true",
-                    help="replay the train step as one captured hipGraph (single process).  Same device-side time as eager launches "
-                         "(17.3 ms on the same box), host enqueue 2 ms instead of 15 ms per step; the last timed step is still launched "
-                         "eagerly to carry the per-launch events, which costs more than it saves at K = 10, so eager stays the default")
+    ap.add_argument("--exec", dest="exec_mode", default="plan", choices=["plan", "graph", "eager"],
+                    help="plan (default): the step is captured once and re-issued from C as plain launches (dm_plan_run; data parallel: "
+                         "segments with the RCCL all-reduce between them); graph: replay the instantiated hipGraph (single process); "
+                         "eager: every launch from Python")
+    ap.add_argument("--graph", dest="graph", action="store_true", help="same as --exec graph")
     ap.add_argument("--shape-table", dest="shape_table", default="", help="write per-shape MFMA launch statistics to this file")
     ap.add_argument("--force-dp", dest="force_dp", action="store_true",
                     help="run the RCCL gradient all-reduce path even with one rank (rehearsal on a 1-GPU box)")
@@ -321,22 +322,36 @@ def main():
     ddpm.rng_seed = 1234 + rank
     x, c, am = synthetic_batch(args.batch, args.size, 4, dev, seed=rank)
 
-    # --graph, single process: the whole step (zero_grad .. AdamW .. weight re-packs) is one captured hipGraph, replayed per
-    # step; data parallel: eager launches (the RCCL all-reduce sits between backward and the optimiser)
-    graphed = D.GraphedTrainStep(ddpm, opt, x, c, am) if (args.graph and not use_dp) else None
-
-    def train_step(eager=False):
-        if graphed is not None and not eager:
-            return graphed()
+    # The step as a function of its static inputs; run eagerly it IS the eager step, captured it becomes the plan / graph.
+    def body(st):
         opt.zero_grad()
         if reducer is not None:
-            reducer.begin()
-        loss = ddpm(x, c, am)
+            reducer.begin(capture=torch.cuda.is_current_stream_capturing())
+        loss = ddpm(st.x, st.c, st.am)
         loss.backward()
         if reducer is not None:
             reducer.finish()
         opt.step()
         return loss
+
+    mode = "graph" if args.graph else args.exec_mode
+    if mode == "graph" and use_dp:
+        raise SystemExit("--exec graph is single-process only (no collective inside a hipGraph here); use --exec plan")
+    graphed = None
+    if mode == "plan":
+        graphed = D.GraphedTrainStep(ddpm, opt, x, c, am, mode="plan", body=body, runner=reducer.replay if reducer is not None else None)
+    elif mode == "graph":
+        graphed = D.GraphedTrainStep(ddpm, opt, x, c, am, mode="graph", body=body)
+
+    class _Static:                              # the eager path's view of the inputs
+        pass
+    static = _Static()
+    static.x, static.c, static.am = x, c, am
+
+    def train_step(eager=False):
+        if graphed is not None and not eager:
+            return graphed()
+        return body(static)
 
     def fence():
         if use_dp:
@@ -344,24 +359,55 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        train_step(eager=(i == 0))         # one eager warm-up step: the instrumented last timed step then finds its memory cached
+        train_step(eager=(i == 0 and graphed is None))
     fence()
-    # HIP-event pairs around every MFMA launch, on the launch stream — recorded during the LAST timed step only: ~540 event
-    # records per step cost ~2 ms of wall time (gaps between kernels), which would otherwise distort `value`
+    # Per-launch HIP events on the launch stream, recorded during the LAST timed step only (~540 event records per step cost ~2 ms
+    # of wall time, which would otherwise distort `value`).  plan: dm_plan_run_timed puts the event pairs around the halo-kernel
+    # launches of the replay; eager / graph: the last step is launched eagerly with torch events around every MFMA launch.
+    planned = graphed is not None and graphed.plan is not None
+    no_events = bool(os.environ.get("DM_BENCH_NO_EVENTS"))
     t0 = time.perf_counter()
     for i in range(args.steps):
-        last = i == args.steps - 1 and not os.environ.get("DM_BENCH_NO_EVENTS")
+        last = i == args.steps - 1 and not no_events
+        if last and planned:
+            plan = graphed.plan
+            if reducer is not None:
+                graphed._runner = lambda pl: reducer.replay(pl, run=lambda a, b: pl.run_timed("halo_kernel", a, b))
+            else:
+                graphed._runner = lambda pl: pl.run_timed("halo_kernel")
+            loss = train_step()
+            graphed._runner = reducer.replay if reducer is not None else None
+            continue
         if last:
             ops.PROFILE_KINDS = ("conv_igemm", "conv_halo", "conv_wgrad") if dtype == torch.bfloat16 else ("igemm_f32", "wgrad_f32")
             ops.PROFILE = []                   # (the instrumented step is launched eagerly: a replayed graph has no per-launch events)
         loss = train_step(eager=last)
-    t_enq = time.perf_counter() - t0       # host time to enqueue the steps (the GPU runs behind it)
+    t_enq = time.perf_counter() - t0       # host time to enqueue the steps (the GPU runs behind it; with a full queue this is back-pressure)
     fence()
     elapsed = time.perf_counter() - t0
-    if rank == 0:
-        print(f"[bench] host enqueue {t_enq / args.steps * 1e3:.2f} ms/step, wall {elapsed / args.steps * 1e3:.2f} ms/step", file=sys.stderr)
     prof, ops.PROFILE = ops.PROFILE or [], None
     prof_steps = 1                         # steps the event records cover
+    timed = []                             # (kind, flops, seconds, shape)
+    if planned and not no_events:
+        res = graphed.plan.timed_results()
+        meta_conv = [m for m in graphed.conv_meta if m[0] == "conv_halo"]
+        meta_wg = [m for m in graphed.conv_meta if m[0] == "wgrad_halo"]
+        got_conv = [r for r in res if "conv3x3_halo_kernel" in r[1]]
+        got_wg = [r for r in res if "wgrad3x3_halo_kernel" in r[1]]
+        if len(got_conv) != len(meta_conv) or len(got_wg) != len(meta_wg):
+            raise SystemExit(f"bench: the plan holds {len(got_conv)}/{len(got_wg)} halo conv/wgrad launches, the capture recorded {len(meta_conv)}/{len(meta_wg)}")
+        timed = [(m[0], m[1], r[2] * 1e-3, m[2]) for m, r in zip(meta_conv, got_conv)] + [("conv_wgrad", m[1], r[2] * 1e-3, m[2]) for m, r in zip(meta_wg, got_wg)]
+    else:
+        timed = [(kind, flops, e0.elapsed_time(e1) * 1e-3, shape) for (kind, flops, e0, e1, shape) in prof]
+    # host cost of ONE step on an idle queue (no back-pressure): what the launch path itself costs
+    torch.cuda.synchronize()
+    th0 = time.perf_counter()
+    loss_extra = train_step()
+    t_host_one = time.perf_counter() - th0
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(f"[bench] exec={mode}: host enqueue {t_enq / args.steps * 1e3:.2f} ms/step under load, {t_host_one * 1e3:.2f} ms for one step on an idle "
+              f"queue; wall {elapsed / args.steps * 1e3:.2f} ms/step", file=sys.stderr)
     if use_dp:
         tt = torch.tensor([elapsed], device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -376,8 +422,7 @@ def main():
     # ---- roofline of the dominant kernel family (implicit-GEMM conv fwd/dgrad + wgrad) from the events
     fl = {"conv_igemm": [0.0, 0.0, 0], "conv_wgrad": [0.0, 0.0, 0]}
     shapes = {}
-    for (kind, flops, e0, e1, shape) in prof:
-        sec = e0.elapsed_time(e1) * 1e-3
+    for (kind, flops, sec, shape) in timed:
         fl.setdefault(kind, [0.0, 0.0, 0])
         fl[kind][0] += flops
         fl[kind][1] += sec
@@ -421,7 +466,9 @@ def main():
                           "launches": fl["conv_wgrad"][2],
                           "algorithmic_tflop_per_step": round(fl["conv_wgrad"][0] / prof_steps / 1e12, 4)},
                 "mfma_time_share_of_step": round((allconv[1] + fl["conv_wgrad"][1]) / prof_steps / (elapsed / args.steps), 4),
-                "events": "HIP events on the launch stream around every MFMA launch of the last timed step"}
+                "events": ("HIP event pairs on the launch stream around every halo-kernel launch of the last timed step (dm_plan_run_timed; the gather-"
+                           "kernel launches are not timed in this mode, so all_dm_conv / wgrad cover the halo kernels only)") if planned else
+                          "HIP events on the launch stream around every MFMA launch of the last timed step"}
 
     # ---- CFG sampling rate (not part of `value`): every rank samples its shard of n = batch x world images (no exchange inside the
     # trajectory); steady-state step rate = difference of two runs, so the one-off graph capture of sample() cancels out
@@ -465,7 +512,7 @@ def main():
                "config": {"workload": "new_scripy.py ContextUnet %dx%d n_feat=%d T=1000 %s, train step batch=%d per GPU (BASELINE configs[%d])"
                                       % (args.size, args.size, args.n_feat, args.dtype, args.batch, 1 if world == 1 else 2),
                           "global_batch": args.batch * world, "bottleneck_k": args.bottleneck_k, "n_classes": 4,
-                          "parallelism": "dp%d" % world, "hipgraph": graphed is not None, "samples_per_s": round(value * args.batch, 2)},
+                          "parallelism": "dp%d" % world, "exec": mode, "host_ms_one_step_idle_queue": round(t_host_one * 1e3, 3), "samples_per_s": round(value * args.batch, 2)},
                "loss": final_loss, "roofline": roofline, "cpu_baseline": cpu, "sample": sample}
         print(json.dumps(out), file=json_out, flush=True)
     if use_dp:

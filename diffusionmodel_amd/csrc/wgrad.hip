@@ -773,6 +773,9 @@ bool wgrad_halo_plan(const DmWgrad* d, int64_t M, WgHP& hp) {
     return true;
 }
 
+static int g_last_wgrad_path = 0;   // 1: the last dm_conv_wgrad launch went to wgrad3x3_halo_kernel
+extern "C" int dm_last_wgrad_path(void) { return g_last_wgrad_path; }
+
 extern "C" int dm_set_wgrad_variant(int variant) {
     // variant >= 64 sets the workgroup target of the pixel split instead (tuning)
     if (variant >= 64) { g_wgrad_blocks = variant; return DM_OK; }
@@ -797,7 +800,9 @@ extern "C" int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream) {
     DM_CHECK_ARG(M < (1ll << 31), "dm_conv_wgrad: M too large");
     DM_CHECK_ARG((int64_t)d->T * cdiv(d->C1 + d->C2, 128) < 65536, "dm_conv_wgrad: grid.y too large");
     WgHP hp;
+    g_last_wgrad_path = 0;
     if (wgrad_halo_plan(d, M, hp)) {
+        g_last_wgrad_path = 1;
         if (d->Wi >= 64) return launch_wgrad_halo<64>(hp, (hipStream_t)stream);
         if (d->Wi == 32) return launch_wgrad_halo<32>(hp, (hipStream_t)stream);
         if (d->Wi == 16) return launch_wgrad_halo<16>(hp, (hipStream_t)stream);

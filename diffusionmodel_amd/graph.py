@@ -13,18 +13,87 @@ is captured once and replayed.
 Constraints: fixed batch shape; single process (no collective inside the capture — use the eager step
 with GradReducer for data parallelism); hyper-parameters are read from the param group between replays.
 """
+import ctypes as C
+
 import torch
 
+from . import _lib as L
 from . import ops
 from ._lib import DmError
 from .modules import _HipBlock
 
 
+class LaunchPlan:
+    """The kernel / memset nodes of a captured (not instantiated) hipGraph, re-issued from C as plain launches on the current
+    stream (include/dm_amd.h, dm_plan_*).  Holds the torch CUDAGraph: its nodes own the argument blocks and its private memory
+    pool owns every tensor the step allocates."""
+
+    def __init__(self, cuda_graph):
+        lib = L.load()
+        self._graph = cuda_graph
+        raw = cuda_graph.raw_cuda_graph()
+        h = C.c_void_p()
+        if lib.dm_plan_from_graph(C.c_void_p(int(raw)), C.byref(h)) != 0:
+            raise DmError("launch plan: " + lib.dm_last_error().decode())
+        self._h = h
+        info = (C.c_int32 * 6)()
+        lib.dm_plan_info(h, info)
+        self.n_ops, self.n_kernels, self.n_memsets, self.n_markers, self.n_skipped, self.n_segments = [int(v) for v in info]
+        self.segment_markers = [int(lib.dm_plan_segment_marker(h, s)) for s in range(self.n_segments)]
+
+    def run(self, first=0, last=None):
+        L.call("dm_plan_run", self._h, int(first), int(self.n_segments - 1 if last is None else last))
+
+    def run_timed(self, substr, first=0, last=None):
+        """run() with a HIP event pair around every kernel whose name contains `substr` (read them with timed_results())."""
+        L.call("dm_plan_run_timed", self._h, int(first), int(self.n_segments - 1 if last is None else last), substr.encode())
+
+    def timed_results(self, cap=8192):
+        """[(op index, kernel name, ms)] of the launches timed since the last call (synchronises the stream)."""
+        ms, op, n = (C.c_float * cap)(), (C.c_int32 * cap)(), C.c_int32(0)
+        L.call("dm_plan_timed_results", self._h, C.cast(ms, C.c_void_p), C.cast(op, C.c_void_p), cap, C.cast(C.byref(n), C.c_void_p))
+        names = self.op_names()
+        return [(int(op[i]), names[op[i]][1], float(ms[i])) for i in range(n.value)]
+
+    def op_names(self):
+        lib = L.load()
+        buf = C.create_string_buffer(512)
+        out = []
+        for i in range(self.n_ops):
+            kind = lib.dm_plan_op_name(self._h, i, buf, 512)
+            out.append((kind, buf.value.decode(errors="replace")))
+        return out
+
+    def foreign_kernels(self):
+        """Kernel names in the plan that are not libdm_amd's (torch-issued elementwise / fill / copy kernels): {name: count}."""
+        tally = {}
+        for kind, nm in self.op_names():
+            if kind == 0 and "at::native" in nm or kind == 0 and "rocclr" in nm or kind == 0 and "at::cuda" in nm:
+                tally[nm] = tally.get(nm, 0) + 1
+        return tally
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.load().dm_plan_destroy(self._h)
+        except Exception:                      # noqa: BLE001 — interpreter shutdown
+            pass
+
+
 class GraphedTrainStep:
-    def __init__(self, ddpm, opt, x, c, attn_mask, warmup=2):
+    """mode="graph": replay the instantiated hipGraph.  mode="plan": the captured graph is never instantiated; its kernel /
+    memset nodes are read back once (dm_plan_from_graph) and every step re-issues them from C as plain stream launches
+    (dm_plan_run: one ctypes call per step) — the host cost of a graph replay without the graph executor's per-node device
+    cost, and segments (dm_plan_marker) between which the host can run collectives (parallel.PlannedDataParallelStep)."""
+
+    def __init__(self, ddpm, opt, x, c, attn_mask, warmup=2, mode="graph", body=None, runner=None):
         if not x.is_cuda:
             raise DmError("GraphedTrainStep needs device tensors")
-        self.ddpm, self.opt = ddpm, opt
+        if mode not in ("graph", "plan"):
+            raise DmError(f"GraphedTrainStep: mode must be 'graph' or 'plan', got {mode!r}")
+        if runner is not None and mode != "plan":
+            raise DmError("GraphedTrainStep: a segment runner needs mode='plan'")
+        self.ddpm, self.opt, self.mode, self._body, self._runner, self.plan = ddpm, opt, mode, body, runner, None
         self.x, self.c, self.am = x.clone(), c.clone(), attn_mask.clone()
         self._specs = [sp for m in ddpm.modules() if isinstance(m, _HipBlock) for sp in m._specs()]
         dev = x.device
@@ -43,9 +112,16 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         before = [sp.nbt_pending for sp in self._specs]
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = self._eager()
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True) if mode == "plan" else torch.cuda.CUDAGraph()
+        ops.PROFILE_META = meta = []               # (kernel family, algorithmic FLOPs, shape) of every MFMA launch, in launch order
+        try:
+            with torch.cuda.graph(self.graph):
+                self.loss = self._eager()
+        finally:
+            ops.PROFILE_META = None
+        self.conv_meta = meta
+        if mode == "plan":
+            self.plan = LaunchPlan(self.graph)
         self._nbt = [sp.nbt_pending - b for sp, b in zip(self._specs, before)]     # BatchNorm batch counters of one step
         with torch.no_grad():
             opt.flat_p.copy_(snap["p"]); opt.exp_avg.copy_(snap["m"]); opt.exp_avg_sq.copy_(snap["v"])
@@ -63,11 +139,21 @@ class GraphedTrainStep:
         self.replays = 0
 
     def _eager(self):
+        if self._body is not None:
+            return self._body(self)
         self.opt.zero_grad()
         loss = self.ddpm(self.x, self.c, self.am)
         loss.backward()
         self.opt.step()
         return loss
+
+    def _replay(self):
+        if self._runner is not None:
+            self._runner(self.plan)
+        elif self.plan is not None:
+            self.plan.run()
+        else:
+            self.graph.replay()
 
     def __call__(self, x=None, c=None, attn_mask=None):
         if x is not None:
@@ -77,7 +163,7 @@ class GraphedTrainStep:
         if attn_mask is not None:
             self.am.copy_(attn_mask, non_blocking=True)
         self.opt.sync_hyper()                              # picks up a changed lr / weight decay (outside the graph)
-        self.graph.replay()
+        self._replay()
         for sp, d in zip(self._specs, self._nbt):          # host-side bookkeeping one replay stands for
             sp.nbt_pending += d
         self.opt._step += 1

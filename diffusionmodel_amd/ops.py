@@ -27,6 +27,7 @@ _CACHE = {}
 ON_WGRAD = None       # parallel.GradReducer: called with the parameter whose main_grad a weight-gradient launch just completed
 PROFILE_KINDS = ("conv_igemm", "conv_wgrad", "igemm_f32", "wgrad_f32")   # bench.py narrows this to the kinds it reports
 PROFILE = None        # bench.py sets this to a list to collect (kind, flops, start_event, end_event, shape)
+PROFILE_META = None   # graph.GraphedTrainStep: (kind, flops, shape) per MFMA launch of the captured step, no events
 
 
 def bump_weight_epoch():
@@ -246,7 +247,11 @@ def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, s
     d.in1, d.in2, d.w = ptr(in1), ptr(in2), w_ptr
     d.scale, d.shift, d.out, d.psum, d.psq = ptr(scale), ptr(shift), ptr(out), ptr(psum), ptr(psq)
     kind = "conv_igemm" if dtype == torch.bfloat16 else "igemm_f32"
-    if PROFILE is None or kind not in PROFILE_KINDS:
+    if PROFILE_META is not None:
+        call("dm_conv", C.byref(d))
+        halo = kind == "conv_igemm" and L.load().dm_last_conv_path() == 1
+        PROFILE_META.append(("conv_halo" if halo else kind, 2.0 * B * Hq * Wq * N * T * (C1 + C2), f"B{B} {Hi}x{Wi} C{C1}+{C2} N{N} T{T} s{sy} t{ty}"))
+    elif PROFILE is None or kind not in PROFILE_KINDS:
         call("dm_conv", C.byref(d))
     else:   # bench.py: HIP events on the launch stream around this launch + its algorithmic FLOPs
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -276,7 +281,11 @@ def _wgrad_call(dy, in1, in2, dw, dbias, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy
         cache[key] = d
     d.dy, d.in1, d.in2, d.dw, d.dbias = ptr(dy), ptr(in1), ptr(in2), ptr(dw), ptr(dbias)
     kind = "conv_wgrad" if dtype == torch.bfloat16 else "wgrad_f32"
-    if PROFILE is None or kind not in PROFILE_KINDS:
+    if PROFILE_META is not None:
+        call("dm_conv_wgrad", C.byref(d))
+        halo = kind == "conv_wgrad" and L.load().dm_last_wgrad_path() == 1
+        PROFILE_META.append(("wgrad_halo" if halo else kind, 2.0 * B * Hq * Wq * N * T * (C1 + C2), f"B{B} {Hi}x{Wi} C{C1}+{C2} N{N} T{T} s{sy}"))
+    elif PROFILE is None or kind not in PROFILE_KINDS:
         call("dm_conv_wgrad", C.byref(d))
     else:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

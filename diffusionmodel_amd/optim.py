@@ -136,7 +136,12 @@ class FusedAdamW(torch.optim.Optimizer):
                     slot[2].synchronize()             # the copy that last read this host buffer has run
             host, table = slot[0], slot[1]
             host[:len(rows)] = torch.tensor(rows, dtype=torch.int64)
-            table[:len(rows)].copy_(host[:len(rows)], non_blocking=True)
+            if capturing:
+                # a library copy kernel reads the pinned host table directly (a torch copy_ would become a memcpy node, which
+                # a launch plan cannot replay: dm_plan_from_graph)
+                call("dm_cast", host.data_ptr(), table.data_ptr(), ops.L.DM_F32, ops.L.DM_F32, 6 * len(rows))
+            else:
+                table[:len(rows)].copy_(host[:len(rows)], non_blocking=True)
             if not capturing:
                 slot[2] = torch.cuda.Event()
                 slot[2].record()

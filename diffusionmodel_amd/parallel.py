@@ -147,7 +147,13 @@ class OverlappedGradReducer:
         red = OverlappedGradReducer(opt)          # after FusedAdamW, before the first step
         opt.zero_grad(); red.begin(); loss.backward(); red.finish(); opt.step()
 
-    One all-reduce per bucket per step: no gradient accumulation over several backward passes in this mode."""
+    One all-reduce per bucket per step: no gradient accumulation over several backward passes in this mode.
+
+    Launch plans (graph.GraphedTrainStep(mode="plan", body=..., runner=red.replay)): inside a stream capture `begin(capture=True)`
+    makes the reducer emit dm_plan_marker launches where it would have started a collective — bucket b complete (marker b), backward
+    pass over (MARK_BACKWARD_DONE), small gradients packed (MARK_SMALL_PACKED) — and `replay(plan)` re-issues the plan segment by
+    segment from C, running the collectives between the segments exactly as the eager path orders them."""
+    MARK_BACKWARD_DONE, MARK_SMALL_PACKED = 100000, 100001
 
     def __init__(self, opt, n_buckets=6, group=None):
         from . import ops
@@ -190,7 +196,10 @@ class OverlappedGradReducer:
         self._pending, self._launched, self._works = [], [], []
 
     # ---- per step ----------------------------------------------------------------------------
-    def begin(self):
+    def begin(self, capture=False):
+        self._capture = bool(capture)
+        if self._capture and not self._learned:
+            raise DmError("OverlappedGradReducer: run one eager step (the observation step) before capturing a plan")
         self._pending = list(self._need)
         self._launched = [False] * len(self.buckets)
         self._works = []
@@ -210,6 +219,10 @@ class OverlappedGradReducer:
 
     def _launch(self, b):
         self._launched[b] = True
+        if getattr(self, "_capture", False):           # recorded as a segment boundary; replay() runs the collective there
+            from ._lib import call
+            call("dm_plan_marker", int(b))
+            return
         bk = self.buckets[b]
         view = self.flat[bk["lo"]:bk["hi"]]
         if self._drain:
@@ -253,6 +266,18 @@ class OverlappedGradReducer:
         self._ops.ON_WGRAD = None
         if not self.active:
             return
+        if getattr(self, "_capture", False):
+            from ._lib import call
+            call("dm_plan_marker", self.MARK_BACKWARD_DONE)
+            small = tuple((off, n) for (p, off, n) in self.opt._slots if p.grad is not None)
+            if small != self._small_key:
+                raise DmError("OverlappedGradReducer: the set of `.grad` parameters changed between the observation step and the capture")
+            self.opt.gather_grads()
+            if self._small_total:
+                self._copy_small(True)
+                call("dm_plan_marker", self.MARK_SMALL_PACKED)
+                self._copy_small(False)
+            return
         if not self._learned:
             self._bucket_of = {k: self._bucket_of_slot[self._slot_of[k]] for k in self._seen if k in self._slot_of}
             self._need = [0] * len(self.buckets)
@@ -286,6 +311,34 @@ class OverlappedGradReducer:
 
     def all_reduce(self):                             # drop-in for GradReducer when nothing was overlapped
         self.finish()
+
+    def replay(self, plan, run=None):
+        """One planned step: the segments of `plan` (graph.LaunchPlan) from C, the collectives of the eager path between them.
+        `run(first, last)` replaces plan.run (bench.py: the timed variant)."""
+        self._capture = False
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+        run = plan.run if run is None else run
+        for s in range(plan.n_segments):
+            run(s, s)
+            m = plan.segment_markers[s]
+            if 0 <= m < len(self.buckets):
+                self._launch(m)
+            elif m == self.MARK_BACKWARD_DONE:
+                for b in range(len(self.buckets)):
+                    if not self._launched[b]:
+                        self._launch(b)
+                for w in self._works:
+                    w.wait()
+                if self._stream is not None:
+                    torch.cuda.current_stream().wait_stream(self._stream)
+                self._works = []
+            elif m == self.MARK_SMALL_PACKED:
+                if self._drain:
+                    torch.cuda.synchronize()
+                dist.all_reduce(self._packed, op=dist.ReduceOp.SUM, group=self.group)
+            elif m != -1:
+                raise DmError(f"OverlappedGradReducer.replay: unknown plan marker {m}")
 
 
 def broadcast_parameters(flat_params, src=0, group=None):

@@ -85,6 +85,8 @@ int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream);
 /* tuning knob: 1 = register staging, 2 = LDS-DMA, 3 (default) = 2 + the halo-resident kernel for 3x3 stride-1 layers
    (needs dm_set_workspace when the pixel range is split over workgroups; falls back to 2 without it) */
 int dm_set_wgrad_variant(int variant);
+/* 1 when the last dm_conv_wgrad launch used the halo-resident 3x3 kernel, 0 for the per-tap kernels (measurement aid) */
+int dm_last_wgrad_path(void);
 /* Caller-owned device scratch (16-byte aligned) the MFMA kernels may use for split partial sums; it must outlive every
    launch that follows.  One stream at a time: launches that use it are ordered by the stream they are issued on. */
 int dm_set_workspace(void* ws, int64_t bytes);
@@ -275,6 +277,32 @@ int dm_attn_mask(const int32_t* boxes, float* out, int B, int S, float lo, float
 /* multi-tensor fp32 copy/add: table_dev[e] = {src_ptr, dst_ptr, count}; gathers the small parameters'
  * gradients into the flat gradient buffer in one launch */
 int dm_scatter_copy(const int64_t* table_dev, int n_entries, int add, dm_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Launch plans: one step of the reference's hot loops (new_scripy.py:777-803 train step; :457-475 sampling step) recorded once
+ * and re-issued from C as PLAIN stream launches.  The caller captures the step on a stream (hipStreamBeginCapture, or torch's
+ * CUDAGraph with keep_graph=True) — the captured hipGraph is never instantiated — and hands the hipGraph_t over:
+ * dm_plan_from_graph reads every kernel / memset node back (function, grid, block, argument block) in dependency order.
+ * Nodes stay owned by the graph: keep it (and the memory pool of the capture) alive as long as the plan.
+ * memcpy / host / child-graph nodes are refused (DM_EUNSUPPORTED): copies inside a planned step go through library kernels.
+ *   dm_plan_marker          launched INSIDE the capture: ends a segment; the host may act between segments on replay
+ *                           (the data-parallel all-reduce of a finished gradient bucket); not replayed itself
+ *   dm_plan_info            info[6] = {ops, kernel launches, memsets, markers, skipped ordering-only nodes, segments}
+ *   dm_plan_segment_marker  id of the marker that ends segment `seg` (-1 for the last segment)
+ *   dm_plan_op_name         kernel name of op `idx` into buf (diagnostics); returns 0 kernel / 1 memset / 2 marker / -1
+ *   dm_plan_run             issue segments [seg_first, seg_last] on `stream`
+ *   dm_plan_run_timed       dm_plan_run with a HIP event pair on `stream` around every kernel whose name contains `substr`
+ *   dm_plan_timed_results   synchronises `stream`; ms_out[i] / op_out[i] = duration and op index of the i-th timed launch since
+ *                           the last call                                                                                    */
+int dm_plan_marker(int id, dm_stream_t stream);
+int dm_plan_from_graph(void* hip_graph, void** plan_out);
+int dm_plan_info(void* plan, int32_t* info6);
+int dm_plan_segment_marker(void* plan, int seg);
+int dm_plan_op_name(void* plan, int idx, char* buf, int cap);
+int dm_plan_run(void* plan, int seg_first, int seg_last, dm_stream_t stream);
+int dm_plan_run_timed(void* plan, int seg_first, int seg_last, const char* substr, dm_stream_t stream);
+int dm_plan_timed_results(void* plan, float* ms_out, int32_t* op_out, int cap, int32_t* n_out, dm_stream_t stream);
+int dm_plan_destroy(void* plan);
 
 #ifdef __cplusplus
 }

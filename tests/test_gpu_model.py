@@ -382,8 +382,10 @@ def math_isfinite(v):
     return math.isfinite(v)
 
 
-def test_graphed_train_step_matches_eager_and_leaves_state_alone():
-    """GraphedTrainStep: (1) warm-up + capture must not change weights, optimiser moments, BatchNorm buffers or RNG
+@pytest.mark.parametrize("mode", ["graph", "plan"])
+def test_graphed_train_step_matches_eager_and_leaves_state_alone(mode):
+    """GraphedTrainStep (mode="graph": hipGraph replay; mode="plan": the captured nodes re-issued from C as plain launches,
+    include/dm_amd.h dm_plan_*): (1) warm-up + capture must not change weights, optimiser moments, BatchNorm buffers or RNG
     counters; (2) replays must train exactly like eager steps.  n_T = 1 and drop_prob = 0 make the torch-RNG draws
     (timesteps, context mask) deterministic, the DDPM noise comes from the Philox kernel's device-side offset in
     both modes, so the two trajectories differ only by fp32 atomic ordering in the small weight-gradient launches."""
@@ -415,7 +417,12 @@ def test_graphed_train_step_matches_eager_and_leaves_state_alone():
     db, ob = make()
     p0, m0 = ob.flat_p.clone(), ob.exp_avg.clone()
     bufs0 = [b.clone() for b in db.buffers()]
-    step = D.GraphedTrainStep(db, ob, x, c, am)
+    step = D.GraphedTrainStep(db, ob, x, c, am, mode=mode)
+    if mode == "plan":
+        pl = step.plan
+        assert pl.n_kernels > 300 and pl.n_segments == 1 and pl.n_markers == 0 and pl.n_ops == pl.n_kernels + pl.n_memsets
+        names = [nm for kind, nm in pl.op_names() if kind == 0]
+        assert any("adamw_kernel" in nm for nm in names) and any("conv" in nm for nm in names)
     assert torch.equal(ob.flat_p, p0) and torch.equal(ob.exp_avg, m0) and ob._step == 0 and int(ob._step_dev.item()) == 0
     assert all(torch.equal(b, b0) for b, b0 in zip(db.buffers(), bufs0))
     assert db._rng_calls == 0 and int(db._rng_dev.item()) == 0
