@@ -267,7 +267,7 @@ def main():
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--n-feat", dest="n_feat", type=int, default=128)
     ap.add_argument("--bottleneck-k", dest="bottleneck_k", type=int, default=4)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"])
     ap.add_argument("--sample-steps", dest="sample_steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
     ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=8)
@@ -304,12 +304,13 @@ def main():
                          "(or run `python bench.py --gpus N` without WORLD_SIZE set: it starts its own ranks)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
     torch.manual_seed(0)                 # identical initial weights on every rank
     net = D.ContextUnet(3, args.n_feat, 4, bottleneck_k=args.bottleneck_k, dtype=dtype)
     ddpm = D.DDPM(net, (1e-4, 0.02), 1000, dev, drop_prob=0.1)
     ddpm.train()
-    opt = D.FusedAdamW(ddpm.parameters(), lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, grad_scale=1.0 / world)
+    opt = D.FusedAdamW(ddpm.parameters(), lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, grad_scale=1.0 / world,
+                       shadow_dtype=dtype if dtype != torch.float32 else torch.bfloat16)
     use_dp = world > 1 or args.force_dp
     # bucketed all-reduce of the flat gradient buffer, each bucket launched as soon as the backward pass has written it
     reducer = parallel.OverlappedGradReducer(opt, n_buckets=args.buckets) if use_dp else None
@@ -328,10 +329,10 @@ def main():
         if reducer is not None:
             reducer.begin(capture=torch.cuda.is_current_stream_capturing())
         loss = ddpm(st.x, st.c, st.am)
-        loss.backward()
+        ddpm.scaler.scale(loss).backward()          # live in fp16 mode only (new_scripy.py:792)
         if reducer is not None:
             reducer.finish()
-        opt.step()
+        ddpm.scaler.step(opt)                       # fp32 / bf16: plain opt.step()
         return loss
 
     mode = "graph" if args.graph else args.exec_mode
@@ -379,7 +380,7 @@ def main():
             graphed._runner = reducer.replay if reducer is not None else None
             continue
         if last:
-            ops.PROFILE_KINDS = ("conv_igemm", "conv_halo", "conv_wgrad") if dtype == torch.bfloat16 else ("igemm_f32", "wgrad_f32")
+            ops.PROFILE_KINDS = ("conv_igemm", "conv_halo", "conv_wgrad") if dtype != torch.float32 else ("igemm_f32", "wgrad_f32")
             ops.PROFILE = []                   # (the instrumented step is launched eagerly: a replayed graph has no per-launch events)
         loss = train_step(eager=last)
     t_enq = time.perf_counter() - t0       # host time to enqueue the steps (the GPU runs behind it; with a full queue this is back-pressure)
@@ -433,13 +434,13 @@ def main():
         with open(args.shape_table, "w") as f:
             for (kind, shape), (flo, sec, n) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                 f.write(f"{sec / prof_steps * 1e3:8.3f} ms/step {n / prof_steps:5.1f}x {sec / n * 1e6:8.1f} us {flo / sec / 1e12:8.1f} TF/s  {kind:11s} {shape}\n")
-    if dtype != torch.bfloat16:
+    if dtype == torch.float32:
         fl["conv_igemm"], fl["conv_wgrad"] = fl.get("igemm_f32", [0.0, 0.0, 0]), fl.get("wgrad_f32", [0.0, 0.0, 0])
     # dominant kernel: conv3x3_halo_kernel (forward + input gradient of the 3x3 layers) when the run used it, else the gather kernel
     fl.setdefault("conv_halo", [0.0, 0.0, 0])
     dom = "conv_halo" if fl["conv_halo"][2] else "conv_igemm"
     allconv = [fl["conv_igemm"][k] + fl["conv_halo"][k] for k in range(3)]
-    peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+    peak = PEAK_BF16_TFLOPS if dtype != torch.float32 else PEAK_F32_TFLOPS     # fp16 and bf16 MFMA run at the same dense rate
     ach = fl[dom][0] / max(fl[dom][1], 1e-12) / 1e12
     # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes over this same
     # command (they cannot be collected from inside the process); the committed summary is quoted when present

@@ -9,8 +9,8 @@ from .config import Cfg, Config  # noqa: F401
 from .ddpm import DDPM, SCHEDULE_KEYS, ddpm_schedules  # noqa: F401
 from .modules import (ContextUnet, CoordAttn, EmbedFC, LocalEnhancer, ResConvBlock, ResidualConvBlock, SEBlock,  # noqa: F401
                       UnetDown, UnetUp)
-from .optim import FusedAdamW  # noqa: F401
+from .optim import DmGradScaler, FusedAdamW  # noqa: F401
 from .graph import GraphedTrainStep  # noqa: F401
 
-__all__ = ["Cfg", "Config", "ContextUnet", "CoordAttn", "DDPM", "DmError", "EmbedFC", "FusedAdamW", "GraphedTrainStep", "LocalEnhancer",
+__all__ = ["Cfg", "Config", "ContextUnet", "CoordAttn", "DDPM", "DmError", "DmGradScaler", "EmbedFC", "FusedAdamW", "GraphedTrainStep", "LocalEnhancer",
            "ResConvBlock", "ResidualConvBlock", "SEBlock", "UnetDown", "UnetUp", "ddpm_schedules"]

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DM_LIB_PATH") or os.path.join(_HERE, "libdm_amd.so")     # (DM_LIB_PATH: experimental builds)
 DEFAULT_CONV_VARIANT = 5      # what libdm_amd.so starts with (igemm.hip g_variant); DM_CONV_VARIANT overrides
 
-DM_F32, DM_BF16 = 0, 1
+DM_F32, DM_BF16, DM_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 
 vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
@@ -92,6 +92,8 @@ _PROTOS = {
     "dm_randn_slice": [vp, i64, u64, u64, i64],
     "dm_sumsq": [vp, i64, vp],
     "dm_adamw": [vp, vp, vp, vp, i64, vp, vp, vp, vp],
+    "dm_adamw_scaled": [vp, vp, vp, vp, i64, vp, vp, vp, i32, vp, vp],
+    "dm_scaler_update": [vp, vp, vp, f32, f32, i32],
     "dm_randn_dev": [vp, i64, u64, vp],
     "dm_pack_multi": [vp, vp, vp, i32],
     "dm_plan_marker": [i32],
@@ -179,7 +181,9 @@ def dt(t_or_dtype):
         return DM_F32
     if d == torch.bfloat16:
         return DM_BF16
-    raise DmError(f"unsupported dtype {d}: the HIP path computes in float32 or bfloat16")
+    if d == torch.float16:
+        return DM_F16
+    raise DmError(f"unsupported dtype {d}: the HIP path computes in float32, bfloat16 or float16")
 
 
 def call(name, *args):

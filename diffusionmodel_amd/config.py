@@ -47,12 +47,13 @@ class Cfg:
     NORM_STD = (0.5, 0.5, 0.5)
     # ---- additions of this implementation (defaults keep the reference's behaviour)
     BOTTLENECK_K = 8
-    DTYPE = "float32"          # "float32" (1e-4 parity mode) or "bfloat16" (throughput mode)
+    DTYPE = "float32"          # "float32" (1e-4 parity mode), "bfloat16" (throughput mode) or "float16" (the reference's autocast dtype, with loss scaling)
     WORLD_SIZE = 1
 
     @classmethod
     def torch_dtype(cls):
-        return {"float32": torch.float32, "fp32": torch.float32, "bfloat16": torch.bfloat16, "bf16": torch.bfloat16}[cls.DTYPE]
+        return {"float32": torch.float32, "fp32": torch.float32, "bfloat16": torch.bfloat16, "bf16": torch.bfloat16,
+                "float16": torch.float16, "fp16": torch.float16, "half": torch.float16}[cls.DTYPE]
 
     @classmethod
     def loss_constants(cls):

@@ -8,6 +8,10 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -42,6 +46,16 @@ template <> struct Elem<bf16> {
     __device__ static inline float ld(const bf16* p) { return (float)*p; }
     __device__ static inline void st(bf16* p, float v) { *p = (bf16)v; }
 };
+
+template <> struct Elem<f16> {
+    static constexpr int VE = 8;
+    __device__ static inline float ld(const f16* p) { return (float)*p; }
+    __device__ static inline void st(f16* p, float v) { *p = (f16)v; }
+};
+// the 2 / 4 / 8-element vector types of a 16-bit storage type (generic epilogues)
+template <typename T> struct V16;
+template <> struct V16<bf16> { typedef bf16x2 x2; typedef bf16x4 x4; typedef bf16x8 x8; };
+template <> struct V16<f16> { typedef f16x2 x2; typedef f16x4 x4; typedef f16x8 x8; };
 
 __device__ inline float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ inline float gelu_grad_f(float x) {
@@ -123,6 +137,11 @@ template <> __device__ inline void load_vec<bf16>(const bf16* p, float* f) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
 }
+template <> __device__ inline void load_vec<f16>(const f16* p, float* f) {
+    const f16x8 v = *(const f16x8*)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
 template <typename T> __device__ inline void store_vec(T* p, const float* f);
 template <> __device__ inline void store_vec<float>(float* p, const float* f) {
     f32x4 v = {f[0], f[1], f[2], f[3]};
@@ -133,6 +152,13 @@ template <> __device__ inline void store_vec<bf16>(bf16* p, const float* f) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (bf16)f[i];
     *(bf16x8*)p = v;
+}
+
+template <> __device__ inline void store_vec<f16>(f16* p, const float* f) {
+    f16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (f16)f[i];
+    *(f16x8*)p = v;
 }
 
 // caller-owned scratch registered through dm_set_workspace (runtime.hip): split partial sums of the MFMA kernels
@@ -150,4 +176,5 @@ static inline int grid_for(int64_t work_items, int block, int cap = 256 * 16) {
 #define DM_DISPATCH_DTYPE(dtype, ...)                          \
     if ((dtype) == DM_F32) { using T = float; __VA_ARGS__; }   \
     else if ((dtype) == DM_BF16) { using T = bf16; __VA_ARGS__; } \
+    else if ((dtype) == DM_F16) { using T = f16; __VA_ARGS__; } \
     else { dm_set_error("bad dtype %d", (int)(dtype)); return DM_EINVAL; }

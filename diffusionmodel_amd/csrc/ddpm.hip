@@ -170,9 +170,13 @@ __global__ void sumsq_kernel(const float* g, int64_t n, float* out) {
 
 // 4 parameters per lane-iteration (16-byte loads / stores of p, g, m, v: 28 B of traffic per parameter, HBM-bound);
 // optionally refreshes the bf16 shadow of the parameters that the conv kernels read (p16[i] = bf16(p[i])).
+// `scaler` (may be null): dynamic loss-scaling state {scale, growth tracker, found_inf of this step, 1 / scale the gradients of this step
+// were produced under} maintained by scaler_update_kernel: a step whose gradients hold inf / nan is SKIPPED (torch.amp.GradScaler.step)
+template <typename T16>
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hy,
-                                                    bf16* p16, const int64_t* step_dev) {
-    const float lr = hy[0], b1 = hy[1], b2 = hy[2], eps = hy[3], wd = hy[4], max_norm = hy[5], gscale = hy[6];
+                                                    T16* p16, const int64_t* step_dev, const float* scaler) {
+    if (scaler && scaler[2] != 0.f) return;
+    const float lr = hy[0], b1 = hy[1], b2 = hy[2], eps = hy[3], wd = hy[4], max_norm = hy[5], gscale = hy[6] * (scaler ? scaler[3] : 1.f);
     float bc1 = hy[7], bc2 = hy[8];
     if (step_dev) {                                    // step count kept on the device (hipGraph replays advance it)
         const double t = (double)*step_dev;
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
         ((f32x4*)m)[i] = mo;
         ((f32x4*)v)[i] = vo;
         ((f32x4*)p)[i] = po;
-        if (p16) ((bf16x4*)p16)[i] = (bf16x4){(bf16)po[0], (bf16)po[1], (bf16)po[2], (bf16)po[3]};
+        if (p16) ((typename V16<T16>::x4*)p16)[i] = (typename V16<T16>::x4){(T16)po[0], (T16)po[1], (T16)po[2], (T16)po[3]};
     }
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {   // tail (< 4 elements)
         const float gg = g[i] * coef;
@@ -212,7 +216,27 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
         v[i] = vv;
         const float po = p[i] * decay - step_size * mm / (sqrtf(vv) * rbc2 + eps);
         p[i] = po;
-        if (p16) p16[i] = (bf16)po;
+        if (p16) p16[i] = (T16)po;
+    }
+}
+
+// torch.amp.GradScaler.update() + the found-inf test of .step(), on the device (one thread): runs after dm_sumsq, before dm_adamw.
+// st = {scale, growth tracker, found_inf, inv_scale}: found_inf = the sum of squares of the (scaled) gradients is not finite;
+// then the optimiser step is skipped (the step count taken back), scale *= backoff, tracker = 0; otherwise tracker += 1 and
+// every `interval` clean steps scale *= growth.  inv_scale = 1 / (the scale this step's gradients carry).
+__global__ void scaler_update_kernel(float* st, const float* sumsq, int64_t* step_dev, float growth, float backoff, int interval) {
+    const float s = st[0];
+    const bool bad = !(sumsq[0] < __builtin_huge_valf());      // inf or nan
+    st[3] = 1.f / s;
+    st[2] = bad ? 1.f : 0.f;
+    if (bad) {
+        st[0] = s * backoff;
+        st[1] = 0.f;
+        if (step_dev) *step_dev -= 1;
+    } else {
+        const float t = st[1] + 1.f;
+        if ((int)t >= interval) { st[0] = s * growth; st[1] = 0.f; }
+        else st[1] = t;
     }
 }
 
@@ -304,7 +328,27 @@ extern "C" int dm_adamw(float* p, const float* g, float* m, float* v, int64_t n,
     static int blocks_env = -1;
     if (blocks_env < 0) { const char* e = getenv("DM_ADAMW_BLOCKS"); blocks_env = e ? atoi(e) : 0; }
     const int blocks = blocks_env > 0 ? blocks_env : grid_for(n / 4 + 1, 256, 16384);
-    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, ST, p, g, m, v, n, sumsq, hyper9, (bf16*)p_bf16, step_dev);
+    hipLaunchKernelGGL(adamw_kernel<bf16>, dim3(blocks), dim3(256), 0, ST, p, g, m, v, n, sumsq, hyper9, (bf16*)p_bf16, step_dev, (const float*)nullptr);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_adamw_scaled(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hyper9, void* p16,
+                               int p16_dtype, const int64_t* step_dev, const float* scaler4, dm_stream_t s) {
+    DM_CHECK_ARG(p && g && m && v && sumsq && hyper9 && n > 0, "dm_adamw_scaled: bad arguments");
+    DM_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && ((uintptr_t)p16 & 7) == 0,
+                 "dm_adamw_scaled: the flat buffers must be 16-byte aligned (the 16-bit shadow 8-byte)");
+    DM_CHECK_ARG(p16 == nullptr || p16_dtype == DM_BF16 || p16_dtype == DM_F16, "dm_adamw_scaled: the shadow is bf16 or fp16");
+    const int blocks = grid_for(n / 4 + 1, 256, 16384);
+    if (p16_dtype == DM_F16) hipLaunchKernelGGL(adamw_kernel<f16>, dim3(blocks), dim3(256), 0, ST, p, g, m, v, n, sumsq, hyper9, (f16*)p16, step_dev, scaler4);
+    else hipLaunchKernelGGL(adamw_kernel<bf16>, dim3(blocks), dim3(256), 0, ST, p, g, m, v, n, sumsq, hyper9, (bf16*)p16, step_dev, scaler4);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_scaler_update(float* state4, const float* sumsq, int64_t* step_dev, float growth, float backoff, int interval, dm_stream_t s) {
+    DM_CHECK_ARG(state4 && sumsq && growth >= 1.f && backoff > 0.f && backoff <= 1.f && interval > 0, "dm_scaler_update: bad arguments");
+    hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(1), 0, ST, state4, sumsq, step_dev, growth, backoff, interval);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

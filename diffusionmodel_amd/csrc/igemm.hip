@@ -84,6 +84,11 @@ template <> struct Mma<bf16> {
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
 };
+template <> struct Mma<f16> {
+    __device__ static inline void run(const u32x4& a, const u32x4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
 template <> struct Mma<float> {
     __device__ static inline void run(const u32x4& a, const u32x4& b, f32x4& c) {
         const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
@@ -186,8 +191,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 
                     unsigned qa[2], qb[2];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const bf16x2 a2 = {(bf16)act_apply_t<T>(acc[2 * pr][mt][2 * h], p.act), (bf16)act_apply_t<T>(acc[2 * pr][mt][2 * h + 1], p.act)};
-                        const bf16x2 b2 = {(bf16)act_apply_t<T>(acc[2 * pr + 1][mt][2 * h], p.act), (bf16)act_apply_t<T>(acc[2 * pr + 1][mt][2 * h + 1], p.act)};
+                        typedef typename V16<T>::x2 t2;
+                        const t2 a2 = {(T)act_apply_t<T>(acc[2 * pr][mt][2 * h], p.act), (T)act_apply_t<T>(acc[2 * pr][mt][2 * h + 1], p.act)};
+                        const t2 b2 = {(T)act_apply_t<T>(acc[2 * pr + 1][mt][2 * h], p.act), (T)act_apply_t<T>(acc[2 * pr + 1][mt][2 * h + 1], p.act)};
                         const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a2), __builtin_bit_cast(unsigned, b2), false, false);
                         qa[h] = sw[0];                     // even rows: own a      | odd rows: partner's b
                         qb[h] = sw[1];                     // even rows: partner's a | odd rows: own b
@@ -223,8 +229,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 
                     if constexpr (sizeof(T) == 4) {
                         *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
                     } else {
-                        bf16x4 q = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                        *(bf16x4*)o = q;
+                        typedef typename V16<T>::x4 t4;
+                        t4 q = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+                        *(t4*)o = q;
                     }
                 } else {
 #pragma unroll
@@ -541,7 +548,7 @@ constexpr int HALO_LDS = 2 * HALO_BYTES + 3 * WSTAGE; // 159,744 B
 constexpr unsigned OOB = 0x80000000u;
 constexpr int SRD_FLAGS = 0x00020000;
 
-template <int TW, bool FLIP>
+template <typename T, int TW, bool FLIP>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
     // TW = 8 (8x8 images): the tile is FOUR whole images laid side by side in the halo, each with its own zero columns
     // ([0 A 0][0 B 0][0 C 0][0 D 0], 10 columns apiece): rows stay multiples of 8 pixels, a wave (64 pixels) is one image
@@ -676,7 +683,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) Mma<bf16>::run(fa[nt], fb[mt], acc[nt][mt]);
+                        for (int mt = 0; mt < 4; ++mt) Mma<T>::run(fa[nt], fb[mt], acc[nt][mt]);
                 }
             }
 #pragma unroll
@@ -698,7 +705,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
     const int tidh = (((wave & 1) + 2 * wn) << 6) + lane;
     // first output pixel of this wave's 64: linear in the tile for whole-row tiles, its own image row for column tiles
     const int mw = (TW == 64 && tcols > 1) ? ((b * p.Hi + y0 + wm4) * p.Wi + x0) : m0 + wm4 * 64;
-    conv_epilogue<bf16, 128>(p, acc, smem + half * 4096, tidh, wm4 & 1, wn, fr, fg, mb * 2 + half, mw - (wm4 & 1) * 64, n0);
+    conv_epilogue<T, 128>(p, acc, smem + half * 4096, tidh, wm4 & 1, wn, fr, fg, mb * 2 + half, mw - (wm4 & 1) * 64, n0);
 }
 
 int g_last_path = 0;  // kernel family the last dm_conv launch used: 0 = gather (conv_igemm*), 1 = conv3x3_halo_kernel
@@ -731,11 +738,11 @@ int launch_bn(const ConvP& p, int64_t grid, int variant, hipStream_t st) {
     return rc;
 }
 
-template <int TW, bool FLIP>
+template <typename T, int TW, bool FLIP>
 int launch_halo(const ConvP& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<TW, FLIP>, hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TW, FLIP>, hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
         if (e != hipSuccess) { dm_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", HALO_LDS, hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
@@ -752,11 +759,11 @@ int launch_halo(const ConvP& p, hipStream_t st) {
             q.ws = dm_g_ws;
         }
     }
-    hipLaunchKernelGGL((conv3x3_halo_kernel<TW, FLIP>), dim3((unsigned)(tiles * q.splits)), dim3(512), HALO_LDS, st, q);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TW, FLIP>), dim3((unsigned)(tiles * q.splits)), dim3(512), HALO_LDS, st, q);
     DM_LAUNCH_CHECK();
     g_last_path = 1;
     if (q.splits > 1) {
-        hipLaunchKernelGGL((splitk_epilogue_kernel<bf16, 128>), dim3((unsigned)(tiles * 2)), dim3(256), 0, st, q);
+        hipLaunchKernelGGL((splitk_epilogue_kernel<T, 128>), dim3((unsigned)(tiles * 2)), dim3(256), 0, st, q);
         DM_LAUNCH_CHECK();
     }
     return DM_OK;
@@ -788,10 +795,10 @@ int launch_conv(const ConvP& p, bool small_offsets, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         if (g_variant == 5 && halo_eligible(p)) {
             const bool flip = p.ty < 0;
-            if (p.Wi >= 64) return flip ? launch_halo<64, true>(p, st) : launch_halo<64, false>(p, st);
-            if (p.Wi == 32) return flip ? launch_halo<32, true>(p, st) : launch_halo<32, false>(p, st);
-            if (p.Wi == 16) return flip ? launch_halo<16, true>(p, st) : launch_halo<16, false>(p, st);
-            return flip ? launch_halo<8, true>(p, st) : launch_halo<8, false>(p, st);
+            if (p.Wi >= 64) return flip ? launch_halo<T, 64, true>(p, st) : launch_halo<T, 64, false>(p, st);
+            if (p.Wi == 32) return flip ? launch_halo<T, 32, true>(p, st) : launch_halo<T, 32, false>(p, st);
+            if (p.Wi == 16) return flip ? launch_halo<T, 16, true>(p, st) : launch_halo<T, 16, false>(p, st);
+            return flip ? launch_halo<T, 8, true>(p, st) : launch_halo<T, 8, false>(p, st);
         }
     }
     const int mblocks = cdiv(p.M, BM);
@@ -847,8 +854,8 @@ extern "C" int dm_get_conv_variant(void) { return g_variant; }
 extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
     DM_CHECK_ARG(d != nullptr, "dm_conv: null descriptor");
     g_last_path = 0;
-    const int ve = d->dtype == DM_BF16 ? 8 : 4;
-    DM_CHECK_ARG(d->dtype == DM_F32 || d->dtype == DM_BF16, "dm_conv: bad dtype %d", d->dtype);
+    const int ve = d->dtype == DM_F32 ? 4 : 8;
+    DM_CHECK_ARG(d->dtype == DM_F32 || d->dtype == DM_BF16 || d->dtype == DM_F16, "dm_conv: bad dtype %d", d->dtype);
     DM_CHECK_ARG(d->in1 && d->w && d->out, "dm_conv: null tensor pointer");
     DM_CHECK_ARG(d->C1 > 0 && d->C1 % ve == 0 && d->C2 >= 0 && d->C2 % ve == 0, "dm_conv: C1=%d C2=%d must be multiples of %d", d->C1, d->C2, ve);
     DM_CHECK_ARG(d->C2 == 0 || d->in2, "dm_conv: C2 > 0 but in2 is null");
@@ -872,7 +879,7 @@ extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
     p.B2 = d->in2_batch > 0 ? d->in2_batch : d->B;
     if (p.B2 != p.B) {                           // broadcast second source: the halo-resident kernel only
         DM_CHECK_ARG(d->C2 > 0 && d->B % p.B2 == 0, "dm_conv: in2_batch=%d must divide B=%d", p.B2, d->B);
-        DM_CHECK_ARG(d->dtype == DM_BF16 && g_variant >= 5 && halo_eligible(p),
+        DM_CHECK_ARG(d->dtype != DM_F32 && g_variant >= 5 && halo_eligible(p),
                      "dm_conv: a broadcast second source (in2_batch) needs the halo-resident 3x3 kernel (bf16, stride 1, 16/32/64-pixel rows)");
     }
     // the LDS-DMA kernel indexes with unsigned 32-bit element offsets (with a margin for the halo arithmetic)
@@ -880,5 +887,6 @@ extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
     const int64_t w_elems = (int64_t)d->N * d->ldw;
     const bool small = in_elems < (1ll << 31) - (1ll << 24) && w_elems < (1ll << 31);
     if (d->dtype == DM_BF16) return launch_conv<bf16>(p, small, (hipStream_t)stream);
+    if (d->dtype == DM_F16) return launch_conv<f16>(p, small, (hipStream_t)stream);
     return launch_conv<float>(p, small, (hipStream_t)stream);
 }

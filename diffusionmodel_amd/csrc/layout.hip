@@ -46,14 +46,14 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const int64_t* __restri
         const int64_t* ent = entries + 8 * (int64_t)e;
         const float* src = (const float*)ent[0];
         const int N = (int)ent[2], Tn = (int)ent[3], C = (int)ent[4], Tt = (int)ent[5], Np = (int)ent[6], dtype = (int)ent[7] & 0xff;
-        const bool src16 = ((int)ent[7] >> 8) != 0;        // the source is the bf16 shadow of the parameter (same element layout): half the read
+        const int src16 = (int)ent[7] >> 8;                // 1 / 2: the source is the bf16 / fp16 shadow of the parameter (same element layout): half the read
         const int ts = taps[16 * e + tt];
         float v[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int n = n0 + ty + 4 * j, c = c0 + tx;
             const size_t i = ((size_t)n * Tn + ts) * C + c;
-            v[j] = (n < N && c < C) ? (src16 ? (float)((const bf16*)src)[i] : src[i]) : 0.f;
+            v[j] = (n < N && c < C) ? (src16 == 1 ? (float)((const bf16*)src)[i] : src16 == 2 ? (float)((const f16*)src)[i] : src[i]) : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) tile[ty + 4 * j][tx] = v[j];
@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const int64_t* __restri
             if (c < C && n < Np) {
                 const size_t o = ((size_t)c * Tt + tt) * Np + n;
                 if (dtype == DM_BF16) ((bf16*)ent[1])[o] = (bf16)tile[tx][ty + 4 * j];
+                else if (dtype == DM_F16) ((f16*)ent[1])[o] = (f16)tile[tx][ty + 4 * j];
                 else ((float*)ent[1])[o] = tile[tx][ty + 4 * j];
             }
         }
@@ -440,11 +441,17 @@ extern "C" int dm_unpad_dw(const float* src, float* dst, int N, int T_, int C, i
 extern "C" int dm_cast(const void* x, void* y, int from_dtype, int to_dtype, int64_t n, dm_stream_t s) {
     DM_CHECK_ARG(x && y && n > 0, "dm_cast: bad arguments");
     const dim3 g(grid_for(n, 256));
-    if (from_dtype == DM_F32 && to_dtype == DM_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), g, dim3(256), 0, ST, (const float*)x, (bf16*)y, n);
-    else if (from_dtype == DM_BF16 && to_dtype == DM_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), g, dim3(256), 0, ST, (const bf16*)x, (float*)y, n);
-    else if (from_dtype == DM_F32 && to_dtype == DM_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, dim3(256), 0, ST, (const float*)x, (float*)y, n);
-    else if (from_dtype == DM_BF16 && to_dtype == DM_BF16) hipLaunchKernelGGL((cast_kernel<bf16, bf16>), g, dim3(256), 0, ST, (const bf16*)x, (bf16*)y, n);
-    else { dm_set_error("dm_cast: bad dtypes %d -> %d", from_dtype, to_dtype); return DM_EINVAL; }
+#define DM_CAST_CASE(FD, FT, TD, TT) \
+    if (from_dtype == FD && to_dtype == TD) { hipLaunchKernelGGL((cast_kernel<FT, TT>), g, dim3(256), 0, ST, (const FT*)x, (TT*)y, n); } else
+    DM_CAST_CASE(DM_F32, float, DM_BF16, bf16)
+    DM_CAST_CASE(DM_BF16, bf16, DM_F32, float)
+    DM_CAST_CASE(DM_F32, float, DM_F32, float)
+    DM_CAST_CASE(DM_BF16, bf16, DM_BF16, bf16)
+    DM_CAST_CASE(DM_F32, float, DM_F16, f16)
+    DM_CAST_CASE(DM_F16, f16, DM_F32, float)
+    DM_CAST_CASE(DM_F16, f16, DM_F16, f16)
+#undef DM_CAST_CASE
+    { dm_set_error("dm_cast: bad dtypes %d -> %d", from_dtype, to_dtype); return DM_EINVAL; }
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

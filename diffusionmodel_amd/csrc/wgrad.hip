@@ -31,7 +31,22 @@ struct WgP {
 
 template <typename T> struct WgCfg;
 template <> struct WgCfg<bf16> { static constexpr int KD = 32, STRIDE = 288; };
+template <> struct WgCfg<f16> { static constexpr int KD = 32, STRIDE = 288; };
 template <> struct WgCfg<float> { static constexpr int KD = 16, STRIDE = 576; };
+
+// 16-bit MFMA on 128-bit fragments (kept as bf16x8 containers; fp16 reinterprets the same bits)
+template <typename T> struct WMma;
+template <> struct WMma<bf16> {
+    __device__ static __forceinline__ f32x4 run(const bf16x8& a, const bf16x8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct WMma<f16> {
+    __device__ static __forceinline__ f32x4 run(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct WMma<float> {      // never called: the fp32 kernels take the v_mfma_f32_16x16x4_f32 branch
+    __device__ static __forceinline__ f32x4 run(const bf16x8&, const bf16x8&, const f32x4& c) { return c; }
+};
 
 __device__ inline bf16x8 tr_frag(const char* tile, int stride, int col_base, int lane) {
     // 16x16x32 operand fragment for 16 channels starting at col_base, transposed read.
@@ -137,7 +152,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
             for (int it = 0; it < 4; ++it)
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt)
-                    acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[it], fb[jt], acc[it][jt], 0, 0, 0);
+                    acc[it][jt] = WMma<T>::run(fa[it], fb[jt], acc[it][jt]);
         } else {
             const int g = lane >> 4, il = lane & 15;
 #pragma unroll
@@ -194,6 +209,7 @@ typedef const __attribute__((address_space(1))) void* gbl_vptr;
 
 template <typename T> struct Wg2Cfg;
 template <> struct Wg2Cfg<bf16> { static constexpr int KD = 64, RB = 256, SPC = 2, RPP = 4; };   // rows per piece
+template <> struct Wg2Cfg<f16> { static constexpr int KD = 64, RB = 256, SPC = 2, RPP = 4; };
 template <> struct Wg2Cfg<float> { static constexpr int KD = 32, RB = 512, SPC = 4, RPP = 2; };
 
 template <typename T>
@@ -337,7 +353,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgP p) {
                 for (int it = 0; it < 4; ++it)
 #pragma unroll
                     for (int jt = 0; jt < 4; ++jt)
-                        acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[it], fb[jt], acc[it][jt], 0, 0, 0);
+                        acc[it][jt] = WMma<T>::run(fa[it], fb[jt], acc[it][jt]);
             }
         } else {
             const int g = lane >> 4, il = lane & 15;
@@ -411,7 +427,7 @@ struct WgHP {
     int ntiles, nchunks, blocks, splits, tiles_per_split;
 };
 
-template <int TW>
+template <typename T, int TW>
 __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
     // TW = 8 (8x8 images): a tile is TWO whole images side by side in the halo ([0 A 0][0 B 0], 10 columns apiece, HS = 24)
     constexpr int R = TW == 8 ? 8 : 128 / TW, HS = TW == 8 ? 24 : TW + 8, HR = R + 2, XP = HR * HS / 8;    // 36 / 30 / 30 / 30 halo pieces
@@ -569,7 +585,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
-                for (int it = 0; it < 4; ++it) acc[it][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[it], fb[t], acc[it][t], 0, 0, 0);
+                for (int it = 0; it < 4; ++it) acc[it][t] = WMma<T>::run(fa[it], fb[t], acc[it][t]);
             // keep the k-steps apart: merged / hoisted halo reads push the kernel past 256 VGPRs, and a scratch reload in the
             // loop waits on vmcnt — i.e. on the next tile's DMA — which serialises staging and compute
             __builtin_amdgcn_sched_barrier(0);
@@ -578,7 +594,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int r = brow + 16 * j;
-                const bf16x4 v = *(const bf16x4*)(sS + r * 256 + (((bcol >> 4) ^ (r & 7)) << 5) + (bcol & 15) * 2);
+                const typename V16<T>::x4 v = *(const typename V16<T>::x4*)(sS + r * 256 + (((bcol >> 4) ^ (r & 7)) << 5) + (bcol & 15) * 2);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bsum[e] += (float)v[e];
             }
@@ -713,16 +729,16 @@ int launch_wgrad(WgP& p, int splitk_req, bool v2_ok, hipStream_t st) {
 
 }  // namespace
 
-template <int TW>
+template <typename T, int TW>
 int launch_wgrad_halo(const WgHP& p, hipStream_t st) {
     constexpr int bytes = 2 * WGH_STAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_halo_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_halo_kernel<T, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) { dm_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", bytes, hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad3x3_halo_kernel<TW>), dim3((unsigned)(p.blocks * p.splits)), dim3(512), bytes, st, p);
+    hipLaunchKernelGGL((wgrad3x3_halo_kernel<T, TW>), dim3((unsigned)(p.blocks * p.splits)), dim3(512), bytes, st, p);
     DM_LAUNCH_CHECK();
     if (p.splits > 1) {
         const int per_split = p.blocks * 8 * 36 * 64;
@@ -743,7 +759,7 @@ int launch_wgrad_halo(const WgHP& p, hipStream_t st) {
 // bf16 3x3 stride-1 pad-1 layer on whole 16/32/64-pixel rows, 64-channel chunks, identity dy mapping, 31-bit byte offsets.
 // Returns true (and fills hp) when the halo kernel can take the launch with the registered workspace.
 bool wgrad_halo_plan(const DmWgrad* d, int64_t M, WgHP& hp) {
-    if (!g_wgrad_halo || d->dtype != DM_BF16 || d->T != 9 || d->KW != 3 || d->sy != 1 || d->sx != 1) return false;
+    if (!g_wgrad_halo || d->dtype == DM_F32 || d->T != 9 || d->KW != 3 || d->sy != 1 || d->sx != 1) return false;
     if (d->ty != 1 || d->tx != 1 || d->oy0 != -1 || d->ox0 != -1) return false;
     if (d->Hq != d->Hi || d->Wq != d->Wi || d->Ho != d->Hq || d->Wo != d->Wq || d->osy != 1 || d->osx != 1 || d->ooy != 0 || d->oox != 0) return false;
     if (d->Wi == 8) {                                                  // two whole 8x8 images per tile
@@ -787,8 +803,8 @@ extern "C" int dm_set_wgrad_variant(int variant) {
 
 extern "C" int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream) {
     DM_CHECK_ARG(d != nullptr, "dm_conv_wgrad: null descriptor");
-    DM_CHECK_ARG(d->dtype == DM_F32 || d->dtype == DM_BF16, "dm_conv_wgrad: bad dtype %d", d->dtype);
-    const int ve = d->dtype == DM_BF16 ? 8 : 4;
+    DM_CHECK_ARG(d->dtype == DM_F32 || d->dtype == DM_BF16 || d->dtype == DM_F16, "dm_conv_wgrad: bad dtype %d", d->dtype);
+    const int ve = d->dtype == DM_F32 ? 4 : 8;
     DM_CHECK_ARG(d->dy && d->in1 && d->dw, "dm_conv_wgrad: null tensor pointer");
     DM_CHECK_ARG(d->C1 > 0 && d->C1 % ve == 0 && d->C2 >= 0 && d->C2 % ve == 0, "dm_conv_wgrad: C1=%d C2=%d must be multiples of %d", d->C1, d->C2, ve);
     DM_CHECK_ARG(d->C2 == 0 || d->in2, "dm_conv_wgrad: C2 > 0 but in2 is null");
@@ -803,10 +819,17 @@ extern "C" int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream) {
     g_last_wgrad_path = 0;
     if (wgrad_halo_plan(d, M, hp)) {
         g_last_wgrad_path = 1;
-        if (d->Wi >= 64) return launch_wgrad_halo<64>(hp, (hipStream_t)stream);
-        if (d->Wi == 32) return launch_wgrad_halo<32>(hp, (hipStream_t)stream);
-        if (d->Wi == 16) return launch_wgrad_halo<16>(hp, (hipStream_t)stream);
-        return launch_wgrad_halo<8>(hp, (hipStream_t)stream);
+        hipStream_t hst = (hipStream_t)stream;
+        if (d->dtype == DM_F16) {
+            if (d->Wi >= 64) return launch_wgrad_halo<f16, 64>(hp, hst);
+            if (d->Wi == 32) return launch_wgrad_halo<f16, 32>(hp, hst);
+            if (d->Wi == 16) return launch_wgrad_halo<f16, 16>(hp, hst);
+            return launch_wgrad_halo<f16, 8>(hp, hst);
+        }
+        if (d->Wi >= 64) return launch_wgrad_halo<bf16, 64>(hp, hst);
+        if (d->Wi == 32) return launch_wgrad_halo<bf16, 32>(hp, hst);
+        if (d->Wi == 16) return launch_wgrad_halo<bf16, 16>(hp, hst);
+        return launch_wgrad_halo<bf16, 8>(hp, hst);
     }
     WgP p;
     p.dy = (const char*)d->dy; p.in1 = (const char*)d->in1; p.in2 = (const char*)d->in2; p.dw = d->dw; p.dbias = d->dbias;
@@ -820,5 +843,6 @@ extern "C" int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream) {
                        in_elems < (1ll << 31) && M * d->ldy < (1ll << 32) && ((uintptr_t)d->dy & 15) == 0 &&
                        ((uintptr_t)d->in1 & 15) == 0 && ((uintptr_t)d->in2 & 15) == 0;
     if (d->dtype == DM_BF16) return launch_wgrad<bf16>(p, d->splitk, v2_ok, (hipStream_t)stream);
+    if (d->dtype == DM_F16) return launch_wgrad<f16>(p, d->splitk, v2_ok, (hipStream_t)stream);
     return launch_wgrad<float>(p, d->splitk, v2_ok, (hipStream_t)stream);
 }

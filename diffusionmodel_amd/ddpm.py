@@ -55,8 +55,10 @@ class DDPM(_HipBlock):
     def __init__(self, nn_model, betas, n_T, device, drop_prob=0.1):
         super().__init__()
         self.nn_model = nn_model.to(device)
-        # the reference owns a GradScaler for fp16 autocast (new_scripy.py:390); fp32/bf16 need none
-        self.scaler = torch.amp.GradScaler("cuda", enabled=False)
+        # the reference owns a GradScaler for its fp16 autocast (new_scripy.py:390); here it is live in float16 mode only
+        # (fp32 / bf16 need no loss scaling) and keeps its state on the device (optim.DmGradScaler)
+        from .optim import DmGradScaler
+        self.scaler = DmGradScaler(enabled=self.nn_model.compute_dtype == torch.float16)
         for k, v in ddpm_schedules(betas[0], betas[1], n_T).items():
             self.register_buffer(k, v.to(device))
         self.n_T = n_T

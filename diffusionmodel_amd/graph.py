@@ -104,6 +104,8 @@ class GraphedTrainStep:
         snap = dict(p=opt.flat_p.clone(), m=opt.exp_avg.clone(), v=opt.exp_avg_sq.clone(), t=opt._step_dev.clone(),
                     rng=ddpm._rng_dev.clone(), bufs=[b.clone() for b in ddpm.buffers()], torch_rng=torch.cuda.get_rng_state(dev),
                     step=opt._step, calls=ddpm._rng_calls, nbt=[sp.nbt_pending for sp in self._specs])
+        scaler = getattr(ddpm, "scaler", None)
+        scal_state = scaler._state_on(dev).clone() if (scaler is not None and scaler.is_enabled()) else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # allocator and cache warm-up off the capture stream
@@ -128,6 +130,8 @@ class GraphedTrainStep:
             opt._step_dev.copy_(snap["t"]); ddpm._rng_dev.copy_(snap["rng"])
             for b, s in zip(ddpm.buffers(), snap["bufs"]):
                 b.copy_(s)
+            if scal_state is not None:
+                scaler._state_on(dev).copy_(scal_state)
         torch.cuda.set_rng_state(snap["torch_rng"], dev)
         opt._step, ddpm._rng_calls = snap["step"], snap["calls"]
         for sp, n in zip(self._specs, snap["nbt"]):
@@ -143,8 +147,13 @@ class GraphedTrainStep:
             return self._body(self)
         self.opt.zero_grad()
         loss = self.ddpm(self.x, self.c, self.am)
-        loss.backward()
-        self.opt.step()
+        scaler = getattr(self.ddpm, "scaler", None)
+        if scaler is not None and scaler.is_enabled():         # float16 mode: new_scripy.py:792-801
+            scaler.scale(loss).backward()
+            scaler.step(self.opt)
+        else:
+            loss.backward()
+            self.opt.step()
         return loss
 
     def _replay(self):

@@ -50,8 +50,8 @@ class _HipBlock(nn.Module):
     compute_dtype = torch.float32
 
     def set_compute_dtype(self, dtype):
-        if dtype not in (torch.float32, torch.bfloat16):
-            raise DmError(f"compute dtype must be float32 or bfloat16, got {dtype}")
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise DmError(f"compute dtype must be float32, bfloat16 or float16, got {dtype}")
         for m in self.modules():
             if isinstance(m, _HipBlock):
                 m.compute_dtype = dtype

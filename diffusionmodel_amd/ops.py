@@ -3,7 +3,8 @@
 Conventions
 -----------
 * activations are NHWC tensors `(B, H, W, C)`, contiguous, dtype float32 ("fp32 mode", exact-fp32 MFMA,
-  the 1e-4 parity mode) or bfloat16 ("bf16 mode", the throughput mode); C % 8 == 0;
+  the 1e-4 parity mode), bfloat16 ("bf16 mode", the throughput mode) or float16 (the reference's autocast dtype; needs the
+  dynamic loss scaling of optim.DmGradScaler); C % 8 == 0;
 * parameters stay fp32 in the reference's shapes (OIHW ...) but in channels_last memory format, i.e.
   physically [O][kh][kw][I] — exactly the K-contiguous row layout the implicit-GEMM kernel reads,
   so fp32 mode uses the master weights in place and bf16 mode needs only an elementwise cast;
@@ -117,10 +118,10 @@ def packed_fwd(w, dtype, cp):
     if dtype == torch.float32 and cp == c:
         return w
     shadow = getattr(w, "_dm_shadow16", None)
-    if shadow is not None and dtype == torch.bfloat16 and cp == c:
+    if shadow is not None and dtype == shadow.dtype and cp == c:
         stamp = (w.data_ptr(), w._version)
         if w._dm_shadow_stamp != stamp:          # modified behind the optimiser's back (load_state_dict, manual init ...)
-            call("dm_cast", ptr(w), ptr(shadow), L.DM_F32, L.DM_BF16, w.numel())
+            call("dm_cast", ptr(w), ptr(shadow), L.DM_F32, dt(shadow), w.numel())
             w._dm_shadow_stamp = stamp
         return shadow
 
@@ -175,8 +176,8 @@ def refresh_packs():
                 continue
             e = len(ents)
             sh = getattr(w, "_dm_shadow16", None)         # bf16 copy of the parameter kept current by the fused optimiser step
-            if sh is not None and dty == L.DM_BF16:
-                ents.append((sh.data_ptr(), out.data_ptr(), n, t, c, len(taps), np_, dty | 0x100))
+            if sh is not None and dty == dt(sh):          # 0x100 / 0x200: the source is the bf16 / fp16 shadow
+                ents.append((sh.data_ptr(), out.data_ptr(), n, t, c, len(taps), np_, dty | (0x100 if dty == L.DM_BF16 else 0x200)))
             else:
                 ents.append((w.data_ptr(), out.data_ptr(), n, t, c, len(taps), np_, dty))
             taps_rows.append(list(taps) + [0] * (16 - len(taps)))
@@ -246,7 +247,7 @@ def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, s
         cache[key] = d
     d.in1, d.in2, d.w = ptr(in1), ptr(in2), w_ptr
     d.scale, d.shift, d.out, d.psum, d.psq = ptr(scale), ptr(shift), ptr(out), ptr(psum), ptr(psq)
-    kind = "conv_igemm" if dtype == torch.bfloat16 else "igemm_f32"
+    kind = "conv_igemm" if dtype != torch.float32 else "igemm_f32"
     if PROFILE_META is not None:
         call("dm_conv", C.byref(d))
         halo = kind == "conv_igemm" and L.load().dm_last_conv_path() == 1
@@ -280,7 +281,7 @@ def _wgrad_call(dy, in1, in2, dw, dbias, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy
         d.N, d.ldy, d.ldw, d.splitk = N, ldy, ldw, splitk
         cache[key] = d
     d.dy, d.in1, d.in2, d.dw, d.dbias = ptr(dy), ptr(in1), ptr(in2), ptr(dw), ptr(dbias)
-    kind = "conv_wgrad" if dtype == torch.bfloat16 else "wgrad_f32"
+    kind = "conv_wgrad" if dtype != torch.float32 else "wgrad_f32"
     if PROFILE_META is not None:
         call("dm_conv_wgrad", C.byref(d))
         halo = kind == "conv_wgrad" and L.load().dm_last_wgrad_path() == 1
@@ -346,7 +347,7 @@ def _running_stats(bn, n):
 def conv_bcast_ok(dtype, B, H, W, C1, C2):
     """Can a 3x3 stride-1 conv read its second source with a smaller batch (DmConv.in2_batch)?  Mirrors halo_eligible() in
     igemm.hip: bf16, whole 64-channel chunks, rows of 16 / 32 / 64 pixels (or multiples of 64), four 8x8 images per tile."""
-    if dtype != torch.bfloat16 or C1 % 64 or C2 % 64 or L.load().dm_get_conv_variant() < 5:
+    if dtype == torch.float32 or C1 % 64 or C2 % 64 or L.load().dm_get_conv_variant() < 5:
         return False
     if W == 8:
         return H == 8 and B % 4 == 0

@@ -18,7 +18,7 @@ class FusedAdamW(torch.optim.Optimizer):
     CHUNK = 16384
 
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, max_grad_norm=1.0,
-                 grad_scale=1.0):
+                 grad_scale=1.0, shadow_dtype=torch.bfloat16):
         params = [p for p in params]
         if not params:
             raise DmError("FusedAdamW: no parameters")
@@ -37,7 +37,9 @@ class FusedAdamW(torch.optim.Optimizer):
         self.total = total
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.flat_p16 = torch.zeros(total, dtype=torch.bfloat16, device=dev)     # bf16 shadow, refreshed by the AdamW kernel
+        if shadow_dtype not in (torch.bfloat16, torch.float16):
+            raise DmError(f"FusedAdamW: the 16-bit parameter shadow is bfloat16 or float16 (the model's compute dtype), got {shadow_dtype}")
+        self.flat_p16 = torch.zeros(total, dtype=shadow_dtype, device=dev)       # 16-bit shadow, refreshed by the AdamW kernel
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self._slots = []
@@ -78,7 +80,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def refresh_shadow(self):
         """Recompute the whole bf16 shadow from the fp32 masters (construction, after a parameter broadcast or any
         other write to `flat_p` that did not go through step())."""
-        call("dm_cast", ptr(self.flat_p), ptr(self.flat_p16), ops.L.DM_F32, ops.L.DM_BF16, self.total)
+        call("dm_cast", ptr(self.flat_p), ptr(self.flat_p16), ops.L.DM_F32, ops.dt(self.flat_p16), self.total)
         for p, _, _ in self._slots:
             if hasattr(p, "_dm_shadow16"):
                 p._dm_shadow_stamp = (p.data_ptr(), p._version)
@@ -152,19 +154,25 @@ class FusedAdamW(torch.optim.Optimizer):
             ops.ZERO_ARENA.recycle()                 # every small gradient accumulator has been copied out: one fill re-zeroes them
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, scaler=None):
+        """clip_grad_norm_(max_grad_norm) + AdamW (new_scripy.py:797-801).  `scaler` (DmGradScaler, fp16 mode): the gradients carry
+        the loss scale; the kernel unscales them, a step with inf / nan gradients is skipped and the scale adapts — all on the device."""
         if closure is not None:
             raise DmError("FusedAdamW.step does not take a closure")
         self.gather_grads()
-        g0 = self.param_groups[0]
-        b1, b2 = g0["betas"]
         self._step += 1
         self.sync_hyper()
         self._step_dev.add_(1)                       # the kernel derives 1 - beta^t from the device-side count
         self._sumsq.zero_()
         call("dm_sumsq", ptr(self.flat_g), self.total, ptr(self._sumsq))
-        call("dm_adamw", ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.total,
-             ptr(self._sumsq), ptr(self._hyper), ptr(self.flat_p16), ptr(self._step_dev))
+        state = None
+        if scaler is not None and scaler.is_enabled():
+            state = scaler._state_on(self.flat_p.device)
+            self._scaled = True                      # a skipped step takes the device-side count back: the host count is then only an upper bound
+            call("dm_scaler_update", ptr(state), ptr(self._sumsq), ptr(self._step_dev), float(scaler._growth_factor), float(scaler._backoff_factor),
+                 int(scaler._growth_interval))
+        call("dm_adamw_scaled", ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.total,
+             ptr(self._sumsq), ptr(self._hyper), ptr(self.flat_p16), ops.dt(self.flat_p16), ptr(self._step_dev), ptr(state))
         ops.bump_weight_epoch()
         ops.refresh_packs()                          # every transposed (input-gradient) weight pack, one launch
 
@@ -208,6 +216,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 group[k] = g0[k]
         group["params"] = list(range(len(self._slots)))
         state = {}
+        if getattr(self, "_scaled", False):            # loss scaling skipped steps on the device: that count is the truth
+            self._step = int(self._step_dev.item())
         if self._step > 0:
             for i, (p, off, n) in enumerate(self._slots):
                 state[i] = {"step": torch.tensor(float(self._step), dtype=torch.float32),
@@ -253,6 +263,77 @@ class FusedAdamW(torch.optim.Optimizer):
         self.refresh_shadow()                          # the masters were most likely just loaded too
         ops.bump_weight_epoch()
         ops.refresh_packs()
+
+
+class DmGradScaler:
+    """torch.amp.GradScaler's surface (the reference owns one as `ddpm.scaler` and drives it at new_scripy.py:792-802:
+    scale(loss).backward(); unscale_(optim); clip_grad_norm_; step(optim); update()) with the state on the DEVICE, so the whole
+    train step stays capturable: {scale, growth tracker, found_inf, 1/scale} live in a 4-float tensor that dm_scaler_update /
+    dm_adamw_scaled read and write.  Defaults are torch's: init 2^16, growth 2.0, backoff 0.5, interval 2000.
+    Only FusedAdamW can be stepped through it (its kernel unscales, clips and skips); enabled=False makes every call a pass-through."""
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
+        self._enabled = bool(enabled)
+        self._init_scale, self._growth_factor, self._backoff_factor, self._growth_interval = float(init_scale), float(growth_factor), float(backoff_factor), int(growth_interval)
+        self._state = None
+
+    def is_enabled(self):
+        return self._enabled
+
+    def _state_on(self, device):
+        if self._state is None or self._state.device != torch.device(device):
+            prev = self._state.cpu() if self._state is not None else torch.tensor([self._init_scale, 0.0, 0.0, 1.0 / self._init_scale])
+            self._state = prev.to(device=device, dtype=torch.float32)
+        return self._state
+
+    def scale(self, outputs):
+        if not self._enabled:
+            return outputs
+        st = self._state_on(outputs.device)
+        return outputs * st[0]
+
+    def unscale_(self, optimizer):
+        """The fused kernel unscales (and clips the unscaled gradient) inside step(); kept for the reference's call sequence."""
+        if self._enabled and not isinstance(optimizer, FusedAdamW):
+            raise DmError("DmGradScaler drives FusedAdamW only (its kernel unscales, clips and skips on the device)")
+
+    def step(self, optimizer, *args, **kwargs):
+        if not self._enabled:
+            return optimizer.step(*args, **kwargs)
+        if not isinstance(optimizer, FusedAdamW):
+            raise DmError("DmGradScaler drives FusedAdamW only (its kernel unscales, clips and skips on the device)")
+        return optimizer.step(scaler=self)
+
+    def update(self, new_scale=None):
+        """The scale was already adapted on the device by step(); an explicit new_scale overrides it."""
+        if self._enabled and new_scale is not None:
+            st = self._state_on(self._state.device if self._state is not None else "cuda")
+            st[0] = float(new_scale)
+            st[1] = 0.0
+
+    def get_scale(self):
+        if not self._enabled:
+            return 1.0
+        return float(self._state[0].item()) if self._state is not None else self._init_scale
+
+    def found_inf_last_step(self):
+        return bool(self._state is not None and self._state[2].item() != 0.0)
+
+    def state_dict(self):
+        if not self._enabled:
+            return {}
+        tracker = int(self._state[1].item()) if self._state is not None else 0
+        return {"scale": self.get_scale(), "growth_factor": self._growth_factor, "backoff_factor": self._backoff_factor,
+                "growth_interval": self._growth_interval, "_growth_tracker": tracker}
+
+    def load_state_dict(self, sd):
+        if not self._enabled or not sd:
+            return
+        self._growth_factor, self._backoff_factor, self._growth_interval = float(sd["growth_factor"]), float(sd["backoff_factor"]), int(sd["growth_interval"])
+        dev = self._state.device if self._state is not None else None
+        self._state = torch.tensor([float(sd["scale"]), float(sd.get("_growth_tracker", 0)), 0.0, 1.0 / float(sd["scale"])])
+        if dev is not None:
+            self._state = self._state.to(dev)
 
 
 _LIVE = weakref.WeakSet()       # optimisers alive in this process (the gradient scratch arena serves exactly one)

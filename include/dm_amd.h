@@ -6,7 +6,7 @@
  * new_scripy.py:70-477 (and MNIST_script.py:31-300).  Each entry point below replaces one family of
  * those calls; the reference call sites are cited per function.  All pointers are DEVICE pointers
  * unless stated otherwise, all activations are NHWC ("channels last", C contiguous), `dtype` is
- * DM_F32 or DM_BF16 for activations/packed weights, master weights / statistics / gradients of
+ * DM_F32, DM_BF16 or DM_F16 for activations/packed weights, master weights / statistics / gradients of
  * parameters are always fp32.  Every function enqueues on `stream` and returns immediately
  * (no host synchronisation, no allocation: hipGraph-capturable).  Return value: 0 on success,
  * a negative DM_E* code on invalid arguments, or a positive hipError_t.
@@ -24,7 +24,7 @@ extern "C" {
 
 typedef void* dm_stream_t; /* hipStream_t */
 
-enum { DM_F32 = 0, DM_BF16 = 1 };
+enum { DM_F32 = 0, DM_BF16 = 1, DM_F16 = 2 };   /* DM_F16: IEEE half — the reference's torch.cuda.amp.autocast() dtype (new_scripy.py:784) */
 enum { DM_ACT_NONE = 0, DM_ACT_GELU = 1, DM_ACT_RELU = 2, DM_ACT_SIGMOID = 3 };
 enum { DM_OK = 0, DM_EINVAL = -1, DM_EUNSUPPORTED = -2 };
 
@@ -265,6 +265,16 @@ int dm_sumsq(const float* g, int64_t n, float* out /* one float, += */, dm_strea
  * kernel and hyper9[7..8] are ignored (lets a captured hipGraph of the train step be replayed) */
 int dm_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hyper9, void* p_bf16,
              const int64_t* step_dev, dm_stream_t s);
+/* dm_adamw with a 16-bit parameter shadow of either kind (p16_dtype DM_BF16 / DM_F16) and dynamic loss scaling
+ * (the reference trains under torch.cuda.amp.autocast() + GradScaler: new_scripy.py:390, 784-802):
+ * scaler4 (device, may be NULL) = {scale, growth tracker, found_inf of this step, 1 / scale of this step's gradients}.
+ * dm_scaler_update — GradScaler.step()'s found-inf test + GradScaler.update() on the device, between dm_sumsq and
+ * dm_adamw_scaled: found_inf = sumsq is inf / nan -> the step is skipped (step_dev taken back by one), scale *= backoff,
+ * tracker = 0; else tracker += 1 and every `interval` clean steps scale *= growth (torch defaults: 2^16, 2.0, 0.5, 2000). */
+int dm_adamw_scaled(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, const float* hyper9, void* p16,
+                    int p16_dtype, const int64_t* step_dev, const float* scaler4, dm_stream_t s);
+int dm_scaler_update(float* state4, const float* sumsq, int64_t* step_dev, float growth, float backoff, int interval, dm_stream_t s);
+
 
 /* Evaluation helpers of the drivers (new_scripy.py:1188-1250): per image pair (a_i, b_i), n_per_image floats each,
  * out[i] = {sum a, sum b, sum a^2, sum b^2, sum ab, min a, min b, n} as 8 doubles — global-statistics SSIM and PSNR

@@ -161,7 +161,8 @@ def train_model(n_classes=4, n_train=64, n_val=16, max_epochs=None, device="cuda
                                            num_workers=Cfg.NUM_WORKERS if data_root else 0)
     val_dl = torch.utils.data.DataLoader(val_ds, batch_size=Cfg.BATCH_SIZE)
     ddpm = build_model(n_classes, device)
-    optim = FusedAdamW(ddpm.parameters(), lr=Cfg.LR, weight_decay=Cfg.WD, max_grad_norm=1.0)       # :715-719 + clip of :798
+    shadow = ddpm.compute_dtype if ddpm.compute_dtype != torch.float32 else torch.bfloat16
+    optim = FusedAdamW(ddpm.parameters(), lr=Cfg.LR, weight_decay=Cfg.WD, max_grad_norm=1.0, shadow_dtype=shadow)   # :715-719 + clip of :798
     scheduler = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(optim, T_0=10, T_mult=2, eta_min=3e-5)
     early_stop = EarlyStop(verbose=not quiet)
     n_epoch = Cfg.N_EPOCH if max_epochs is None else max_epochs
@@ -195,9 +196,11 @@ def train_model(n_classes=4, n_train=64, n_val=16, max_epochs=None, device="cuda
         for it, (x, c, am) in enumerate(train_dl):
             loss = ddpm(x.to(device), c.long().to(device), to_mask(am)) / Cfg.ACCUM_STEPS   # :784-786
             losses.append(loss.detach())
-            loss.backward()                                                                # :792 (bf16 / fp32: no loss scaling)
+            ddpm.scaler.scale(loss).backward()                                             # :792 (live in float16 mode only)
             if (it + 1) % Cfg.ACCUM_STEPS == 0 or it + 1 == len(train_dl):                 # :795: also flush a short tail group
-                optim.step()                                                               # clip 1.0 + AdamW, fused (:797-801)
+                ddpm.scaler.unscale_(optim)                                                # :797 (the fused kernel unscales + clips 1.0, :798)
+                ddpm.scaler.step(optim)                                                    # :800: skipped on the device when a gradient is inf / nan
+                ddpm.scaler.update()                                                       # :801
                 optim.zero_grad()                                                          # :803
         vals = [float(v) * Cfg.ACCUM_STEPS for v in torch.stack(losses).tolist()]          # one readback per epoch (:789 reads every step)
         for v in vals:
@@ -323,7 +326,7 @@ def main(argv=None):
     ap.add_argument("--n_T", type=int, default=None)
     ap.add_argument("--epochs", type=int, default=None)
     ap.add_argument("--batch_size", type=int, default=None)
-    ap.add_argument("--dtype", choices=["float32", "bfloat16"], default=None)
+    ap.add_argument("--dtype", choices=["float32", "bfloat16", "float16"], default=None)
     ap.add_argument("--bottleneck_k", type=int, default=None)
     ap.add_argument("--data_root", default=None, help="dataset in the reference's layout (images/<class>/*.jpg + annotations/*.xml); "
                                                       "default: synthetic tensors")

@@ -277,6 +277,7 @@ def main():
     gen_mnist(M)
     gen_metrics_and_masks(R)
     gen_bf16_autocast(R)
+    gen_bf16_autocast(R, lp=torch.float16, fname="fp16_autocast.npz")
     gen_train3(R)
     gen_train3(R, autocast=True)
     # key schema of the full-size nets (shapes only; no tensors are instantiated for the big ones)
@@ -355,10 +356,12 @@ def _cos(a, b):
     return float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
 
 
-def gen_bf16_autocast(R, S=64, k=4, nf=32, ncls=4):
+def gen_bf16_autocast(R, S=64, k=4, nf=32, ncls=4, lp=torch.bfloat16, fname="bf16_autocast.npz"):
     """The REFERENCE under torch.autocast("cpu", dtype=torch.bfloat16) — the precision mode BASELINE configs[1] is quoted in
     (new_scripy.py:784 wraps DDPM.forward in autocast) — next to the same reference code in float64, on the unet32_64 and
-    ddpm_fwd64 cases.  Pins what "bf16 parity" means: the reference's own bf16 error (eps MSE, loss, per-child gradient
+    ddpm_fwd64 cases.  Called a second time with lp=torch.float16 -> fp16_autocast.npz (the dtype torch.cuda.amp.autocast() picks on
+    a GPU, i.e. what the reference actually trains in there; the key names keep the "_bf16" suffix = "the autocast run").
+    Pins what "bf16 parity" means: the reference's own bf16 error (eps MSE, loss, per-child gradient
     norm ratio and cosine against fp64) is the yardstick the HIP bf16 path is held to (tests/test_gpu_bf16.py)."""
     out = {}
     # ---- (a) denoiser alone, eval + train
@@ -386,11 +389,14 @@ def gen_bf16_autocast(R, S=64, k=4, nf=32, ncls=4):
         net.load_state_dict(init)
         net.train(train)
         net.zero_grad()
-        with torch.autocast("cpu", dtype=torch.bfloat16):
+        with torch.autocast("cpu", dtype=lp):
             e16 = net(x, c, t, mk)
             l16 = (e16.float() * probe).mean()
-        l16.backward()
-        g16 = _per_child_grads(net)
+        # float16: backward under the GradScaler's initial loss scale (new_scripy.py:390,792: scaler.scale(loss).backward(), then
+        # unscale_) — unscaled fp16 gradients of this size underflow; bfloat16 needs no scaling
+        ls = 65536.0 if lp == torch.float16 else 1.0
+        (l16 * ls).backward()
+        g16 = {cn: v / ls for cn, v in _per_child_grads(net).items()}
         e16 = e16.detach().float()
         out[f"unet.{mode}.eps_bf16"] = e16.numpy()
         out[f"unet.{mode}.eps64"] = e64.detach().numpy()
@@ -435,14 +441,15 @@ def gen_bf16_autocast(R, S=64, k=4, nf=32, ncls=4):
                     mock.patch.object(torch, "randn_like", lambda v, **kw: inj.randn_like(v).to(v.dtype)), \
                     mock.patch.object(torch, "bernoulli", lambda p, **kw: inj.bernoulli(p).to(p.dtype)):
                 if prec == "bf16":
-                    with torch.autocast("cpu", dtype=torch.bfloat16):      # new_scripy.py:784
+                    with torch.autocast("cpu", dtype=lp):                  # new_scripy.py:784
                         loss = ddpm(xin, c, am)
                 else:
                     loss = ddpm(xin, c, am.double())
             res[prec] = float(loss.item())
             if train:
-                loss.backward()
-                res["g" + prec] = _per_child_grads(ddpm.nn_model)
+                ls = 65536.0 if (prec == "bf16" and lp == torch.float16) else 1.0
+                (loss * ls).backward()
+                res["g" + prec] = {cn: v / ls for cn, v in _per_child_grads(ddpm.nn_model).items()}
         ddpm.float()
         net.__dict__.pop("forward", None)
         out[f"ddpm.{mode}.loss64"], out[f"ddpm.{mode}.loss_bf16"] = np.float64(res["64"]), np.float64(res["bf16"])
@@ -452,7 +459,7 @@ def gen_bf16_autocast(R, S=64, k=4, nf=32, ncls=4):
                 out[f"ddpm.train.gn_bf16.{cn}"] = np.float64(res["gbf16"][cn].norm().item())
                 out[f"ddpm.train.cos_bf16.{cn}"] = np.float64(_cos(res["gbf16"][cn], res["g64"][cn]))
         print("bf16 autocast ddpm", mode, res["64"], res["bf16"])
-    np.savez_compressed(os.path.join(OUT, "bf16_autocast.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
 def gen_train3(R, S=64, k=4, nf=32, ncls=4, B=2, n_T=1000, accum=2, n_opt=3, lr=1e-4, wd=1e-5, autocast=False):
@@ -531,6 +538,7 @@ if __name__ == "__main__":
     elif os.environ.get("DM_GOLDEN_ONLY") == "r02":        # the round-2 additions only (schema.json gets the new key merged in)
         R_ = _refload.load("new_scripy")
         gen_bf16_autocast(R_)
+        gen_bf16_autocast(R_, lp=torch.float16, fname="fp16_autocast.npz")
         gen_train3(R_)
         gen_train3(R_, autocast=True)
         with open(os.path.join(OUT, "schema.json")) as f:

@@ -87,10 +87,21 @@ def grad_table(hip_vecs, ref_vecs, skip=("local_enhance",)):
     return t
 
 
+def _autocast_fixture(dtype):
+    """The reference's autocast run that is the yardstick for `dtype` (float32 runs are listed next to the bf16 one)."""
+    return npz("fp16_autocast" if dtype == torch.float16 else "bf16_autocast")
+
+
+def _loss_scale(dtype):
+    """float16 gradients are produced under the GradScaler's initial scale and unscaled afterwards (new_scripy.py:792-797)."""
+    return 65536.0 if dtype == torch.float16 else 1.0
+
+
 def unet_case(dtype, modes=("eval", "train")):
     """HIP ContextUnet(F=32) at 64x64 on the unet32_64 inputs against the reference's float64 run."""
     tag = "unet32_64"
-    g, gb = npz(tag), npz("bf16_autocast")
+    g, gb = npz(tag), _autocast_fixture(dtype)
+    ls = _loss_scale(dtype)
     x = si(tag + ".x", (2, 3, 64, 64))
     c, t, mk = torch.tensor(g["c"]), torch.tensor(g["t"]), torch.tensor(g["ctx_mask"])
     probe = si(tag + ".probe", (2, 3, 64, 64))
@@ -101,7 +112,7 @@ def unet_case(dtype, modes=("eval", "train")):
         net.train(train)
         eps = net(x.to(DEV), c.to(DEV), t.to(DEV), mk.to(DEV))
         loss = (eps * probe.to(DEV)).mean()
-        loss.backward()
+        (loss * ls).backward()
         e = eps.detach().cpu().double().numpy()
         e64 = gb[f"unet.{mode}.eps64"]
         # float64 oracle gradients (the oracle equals the reference in float64 to 3e-13, tests/test_oracle_golden.py)
@@ -115,7 +126,7 @@ def unet_case(dtype, modes=("eval", "train")):
             "ref_autocast_bf16_mse": float(gb[f"unet.{mode}.mse_bf16_vs_64"]), "ref_autocast_bf16_maxabs": float(gb[f"unet.{mode}.maxabs_bf16_vs_64"]),
             "loss": float(loss.item()), "loss_ref64": float(gb[f"unet.{mode}.loss64"]), "loss_ref_autocast_bf16": float(gb[f"unet.{mode}.loss_bf16"]),
             "probe_power": float((probe ** 2).mean()), "n_elements": int(probe.numel()),
-            "grads": grad_table(child_grad_vectors(net), ref_vecs),
+            "grads": grad_table({cn: v / ls for cn, v in child_grad_vectors(net).items()}, ref_vecs),
             "ref_autocast_bf16_grads": {cn: {"norm_rel_err": float(gb[f"unet.{mode}.gn_bf16.{cn}"] / gb[f"unet.{mode}.gn64.{cn}"] - 1.0),
                                              "one_minus_cos": float(1.0 - gb[f"unet.{mode}.cos_bf16.{cn}"])}
                                         for cn in ref_vecs if cn != "local_enhance" and float(gb[f"unet.{mode}.gn64.{cn}"]) > 0},
@@ -127,7 +138,8 @@ def ddpm_case(dtype):
     """HIP DDPM.forward on the ddpm_fwd64 case (draws injected) against the reference's float64 run."""
     import diffusionmodel_amd as D
     tag, B, S, n_T = "ddpm_fwd64", 4, 64, 1000
-    g, gb = npz(tag), npz("bf16_autocast")
+    g, gb = npz(tag), _autocast_fixture(dtype)
+    ls = _loss_scale(dtype)
     x = si(tag + ".x", (B, 3, S, S))
     c = torch.tensor([(i + 2) % 4 for i in range(B)])
     am = synth.synth_attn_mask(B, S)
@@ -144,14 +156,15 @@ def ddpm_case(dtype):
         loss = ddpm(x.to(DEV), c.to(DEV), am.to(DEV), ts=ts.to(DEV), noise=noise.to(DEV), ctx_mask=keep.to(DEV))
         rec = {"loss": float(loss.item()), "loss_ref64": float(gb[f"ddpm.{mode}.loss64"]), "loss_ref_autocast_bf16": float(gb[f"ddpm.{mode}.loss_bf16"])}
         if mode == "train":
-            loss.backward()
+            ddpm.scaler.scale(loss).backward()         # float16: x 2^16 (DmGradScaler's initial scale); fp32 / bf16: pass-through
+            assert ddpm.scaler.get_scale() == ls
             P = synth_state(tag, torch.float64)
             sched = {k: v.double() for k, v in O.ddpm_schedules(1e-4, 0.02, n_T).items()}
             lo = O.ddpm_loss(P, sched, n_T, x.double(), c, am.double(), ts, noise.double(), keep.double(), True)
             lo.backward()
             rec["loss_oracle64"] = float(lo.item())
             ref_vecs = oracle_child_vectors(P, _names_by_child(ddpm.nn_model, "nn_model."))
-            rec["grads"] = grad_table(child_grad_vectors(ddpm.nn_model), ref_vecs)
+            rec["grads"] = grad_table({cn: v / ls for cn, v in child_grad_vectors(ddpm.nn_model).items()}, ref_vecs)
             rec["ref_autocast_bf16_grads"] = {cn: {"norm_rel_err": float(gb[f"ddpm.train.gn_bf16.{cn}"] / gb[f"ddpm.train.gn64.{cn}"] - 1.0),
                                                    "one_minus_cos": float(1.0 - gb[f"ddpm.train.cos_bf16.{cn}"])}
                                               for cn in ref_vecs if cn != "local_enhance" and float(gb[f"ddpm.train.gn64.{cn}"]) > 0}
@@ -227,7 +240,8 @@ def train3_case(dtype):
         sd[k] = D.ddpm_schedules(1e-4, 0.02, n_T)[k]
     ddpm.load_state_dict(sd)
     ddpm.train()
-    opt = D.FusedAdamW(ddpm.parameters(), lr=lr, weight_decay=wd, max_grad_norm=1.0)
+    opt = D.FusedAdamW(ddpm.parameters(), lr=lr, weight_decay=wd, max_grad_norm=1.0,
+                       shadow_dtype=dtype if dtype != torch.float32 else torch.bfloat16)
     losses, norms = [], []
     opt.zero_grad()
     for m in range(accum * n_opt):
@@ -238,10 +252,12 @@ def train3_case(dtype):
         noise = synth.synth_noise(tag + ".noise", (B, 3, S, S)).to(DEV)
         loss = ddpm(x, c, am, ts=torch.tensor(g[f"ts.{m}"]).to(DEV), noise=noise, ctx_mask=torch.tensor(g[f"keep.{m}"]).to(DEV)) / accum
         losses.append(float(loss.item()) * accum)
-        loss.backward()
+        ddpm.scaler.scale(loss).backward()                                               # new_scripy.py:792
         if (m + 1) % accum == 0:
-            opt.step()
-            norms.append(float(opt.grad_norm().item()))
+            ddpm.scaler.unscale_(opt)
+            ddpm.scaler.step(opt)                                                          # :797-801
+            ddpm.scaler.update()
+            norms.append(float(opt.grad_norm().item()) / _loss_scale(dtype))
             opt.zero_grad()
     named = dict(ddpm.named_parameters())
     rec = {"losses": losses, "losses_ref": [float(v) for v in g["losses"]], "grad_norms": norms, "grad_norms_ref": [float(v) for v in g["grad_norms"]]}
@@ -333,9 +349,9 @@ def bn_bwd_kernel_case():
 
 
 def measure_all():
-    out = {"unet32_64": {"bf16": unet_case(torch.bfloat16), "fp32": unet_case(torch.float32)},
-           "ddpm_fwd64": {"bf16": ddpm_case(torch.bfloat16), "fp32": ddpm_case(torch.float32)},
+    out = {"unet32_64": {"bf16": unet_case(torch.bfloat16), "fp16": unet_case(torch.float16), "fp32": unet_case(torch.float32)},
+           "ddpm_fwd64": {"bf16": ddpm_case(torch.bfloat16), "fp16": ddpm_case(torch.float16), "fp32": ddpm_case(torch.float32)},
            "f128_b8_bf16_vs_oracle_fp32": f128_case(),
-           "train3": {"fp32": train3_case(torch.float32), "bf16": train3_case(torch.bfloat16)},
+           "train3": {"fp32": train3_case(torch.float32), "bf16": train3_case(torch.bfloat16), "fp16": train3_case(torch.float16)},
            "conv_bn_gelu_kernel_bf16": bn_bwd_kernel_case()}
     return out

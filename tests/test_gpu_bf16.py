@@ -122,3 +122,84 @@ def test_three_optimiser_steps_bf16_tracks_fp32_and_the_references_bf16_run():
     assert max(r["grad_norm_rel_err"]) <= 2 * max(r["ref_autocast_grad_norm_rel_dev"]) + 0.02
     assert max(abs(v) for v in r["param_norm_rel_err"].values()) <= 1e-4
     assert all(math.isfinite(v) for v in r["losses"])
+
+
+# ---- float16: the dtype torch.cuda.amp.autocast() picks on a GPU (new_scripy.py:784), with the reference's GradScaler (:390, :792-802) ----
+@pytest.fixture(scope="module")
+def unet_f16():
+    return PL.unet_case(torch.float16)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_fp16_eps_mse_within_the_references_own_fp16_error(unet_f16, mode):
+    """Yardstick: tests/golden/fp16_autocast.npz — the reference under torch.autocast("cpu", float16), gradients under the
+    GradScaler's initial 2^16 loss scale.  Measured (profiles/r02_parity.json): HIP 3.0e-7 / 9.0e-5 vs the reference's 4.4e-7 / 1.4e-4."""
+    r = unet_f16[mode]
+    print(f"fp16 {mode}: HIP eps MSE {r['eps_mse_vs_ref64']:.3e} vs reference-autocast {r['ref_autocast_bf16_mse']:.3e}")
+    assert r["eps_mse_vs_ref64"] <= MARGIN * r["ref_autocast_bf16_mse"]
+    assert r["eps_maxabs_vs_ref64"] <= 1.5 * r["ref_autocast_bf16_maxabs"]
+    assert abs(r["loss"] - r["loss_ref64"]) <= 3 * _projection_noise(r["ref_autocast_bf16_mse"], r["probe_power"], r["n_elements"])
+    ref = r["ref_autocast_bf16_grads"]
+    worst_ref_norm = max(abs(v["norm_rel_err"]) for v in ref.values())
+    for cn, v in r["grads"].items():                 # loss-scaled backward, unscaled gradients: all 19 children
+        assert abs(v["norm_rel_err"]) <= worst_ref_norm, (mode, cn, v)
+        assert v["one_minus_cos"] <= 2.0 * ref[cn]["one_minus_cos"] + 1e-5, (mode, cn, v, ref[cn])
+
+
+def test_fp16_ddpm_forward_and_three_optimiser_steps_through_the_loss_scaler():
+    r = PL.ddpm_case(torch.float16)
+    for mode in ("train", "eval"):
+        rel = abs(r[mode]["loss"] - r[mode]["loss_ref64"]) / abs(r[mode]["loss_ref64"])
+        assert rel <= 3e-4, (mode, rel)              # measured 7.5e-6 / 6.8e-5; the reference's own fp16 autocast run: 4.2e-5 / 7.2e-5
+    g, ref = r["train"]["grads"], r["train"]["ref_autocast_bf16_grads"]
+    worst_ref_norm = max(abs(v["norm_rel_err"]) for v in ref.values())
+    for cn, v in g.items():
+        assert abs(v["norm_rel_err"]) <= max(worst_ref_norm, 0.02), (cn, v)
+        assert v["one_minus_cos"] <= 2.0 * ref[cn]["one_minus_cos"] + 1e-4, (cn, v, ref[cn])
+    t = PL.train3_case(torch.float16)                # ddpm.scaler.scale(loss).backward(); unscale_; step; update — new_scripy.py:792-801
+    print("fp16 train3 losses", t["losses"], "ref fp32", t["losses_ref"], "grad norms", t["grad_norms"], t["grad_norms_ref"])
+    assert max(t["loss_rel_err"]) <= 3e-3 and max(t["grad_norm_rel_err"]) <= 3e-2       # measured 1.1e-3 / 1.5e-2
+    assert all(v["step"] == 3.0 for v in t["tensors"].values())                          # no step was skipped
+
+
+def test_loss_scaler_skips_overflowed_steps_and_adapts_the_scale():
+    """torch.amp.GradScaler semantics on the device: inf / nan gradients -> the step is skipped (weights, moments and the step count
+    stay), scale x0.5, tracker 0; `interval` clean steps in a row -> scale x2."""
+    import diffusionmodel_amd as D
+    torch.manual_seed(0)
+    net = D.ContextUnet(3, 32, 4, bottleneck_k=4, dtype=torch.float16)
+    ddpm = D.DDPM(net, (1e-4, 0.02), 50, "cuda:0", drop_prob=0.1)
+    ddpm.train()
+    assert ddpm.scaler.is_enabled() and ddpm.scaler.get_scale() == 65536.0
+    ddpm.scaler = D.DmGradScaler(growth_interval=2)
+    opt = D.FusedAdamW(ddpm.parameters(), lr=1e-3, shadow_dtype=torch.float16)
+    x = torch.randn(2, 3, 64, 64, device="cuda:0").clamp(-1, 1)
+    c = torch.tensor([0, 1], device="cuda:0")
+    am = torch.ones(2, 64, 64, device="cuda:0")
+
+    def one(poison=False):
+        opt.zero_grad()
+        ddpm.scaler.scale(ddpm(x, c, am)).backward()
+        if poison:
+            opt.flat_g[7] = float("inf")
+        ddpm.scaler.unscale_(opt)
+        ddpm.scaler.step(opt)
+        ddpm.scaler.update()
+    one()
+    assert int(opt._step_dev.item()) == 1 and ddpm.scaler.get_scale() == 65536.0 and not ddpm.scaler.found_inf_last_step()
+    p1, m1 = opt.flat_p.clone(), opt.exp_avg.clone()
+    one(poison=True)
+    assert ddpm.scaler.found_inf_last_step() and ddpm.scaler.get_scale() == 32768.0
+    assert int(opt._step_dev.item()) == 1 and torch.equal(opt.flat_p, p1) and torch.equal(opt.exp_avg, m1)
+    one()
+    assert ddpm.scaler.get_scale() == 32768.0 and int(opt._step_dev.item()) == 2 and not torch.equal(opt.flat_p, p1)
+    one()
+    assert ddpm.scaler.get_scale() == 65536.0 and int(opt._step_dev.item()) == 3            # two clean steps in a row: x2
+    assert opt.state_dict()["state"][0]["step"].item() == 3.0                               # the device-side count is what is saved
+    sd = ddpm.scaler.state_dict()
+    assert sd["scale"] == 65536.0 and sd["growth_interval"] == 2 and sd["_growth_tracker"] == 0
+    assert torch.isfinite(opt.flat_p).all()
+    # a disabled scaler (fp32 / bf16 models) is a pass-through
+    off = D.DmGradScaler(enabled=False)
+    t = torch.ones(1, device="cuda:0")
+    assert off.scale(t) is t and off.get_scale() == 1.0 and off.state_dict() == {}

@@ -329,3 +329,30 @@ def test_adamw_state_dict_schema_fixture_matches_torch():
     assert sorted(sd["state"][0].keys()) == sch["state_keys"] and str(sd["state"][0]["step"].dtype) == sch["state0"]["step"][1]
     from diffusionmodel_amd.optim import FusedAdamW
     assert set(FusedAdamW._GROUP_DEFAULTS) | {"lr", "betas", "eps", "weight_decay", "params"} == set(sch["param_group_keys"])
+
+
+def test_grad_scaler_surface_matches_torch_and_is_inert_when_disabled():
+    """ddpm.scaler (new_scripy.py:390): the methods the reference's train loop calls (:792-802) exist with torch's names and
+    defaults; on a model that does not compute in float16 it is disabled and passes everything through."""
+    s = D.DmGradScaler()
+    ref = torch.amp.GradScaler("cpu", enabled=True)
+    for name in ("scale", "unscale_", "step", "update", "get_scale", "is_enabled", "state_dict", "load_state_dict"):
+        assert callable(getattr(s, name)) and callable(getattr(ref, name))
+    assert s.get_scale() == 65536.0 and (s._growth_factor, s._backoff_factor, s._growth_interval) == (2.0, 0.5, 2000)
+    assert set(s.state_dict()) == {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}
+    s2 = D.DmGradScaler()
+    s2.load_state_dict({"scale": 1024.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 7, "_growth_tracker": 3})
+    assert s2.get_scale() == 1024.0 and s2.state_dict()["_growth_tracker"] == 3 and s2.state_dict()["growth_interval"] == 7
+    ddpm = D.DDPM(D.ContextUnet(3, 32, 4, bottleneck_k=4), (1e-4, 0.02), 10, "cpu")
+    assert not ddpm.scaler.is_enabled() and ddpm.scaler.get_scale() == 1.0
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(2))], lr=0.1)
+    t = torch.ones(())
+    assert ddpm.scaler.scale(t) is t
+    ddpm.scaler.unscale_(opt)
+    ddpm.scaler.step(opt)
+    ddpm.scaler.update()
+    with pytest.raises(D.DmError):
+        D.DmGradScaler().step(opt)                   # an enabled scaler drives FusedAdamW only
+    with pytest.raises(D.DmError):
+        D.ContextUnet(3, 32, 4, dtype=torch.float64)
+    assert D.ContextUnet(3, 32, 4, dtype=torch.float16).compute_dtype == torch.float16
