@@ -22,7 +22,8 @@ vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 class DmConv(C.Structure):
     _fields_ = [(n, vp) for n in ("in1", "in2", "w", "scale", "shift", "out", "psum", "psq")] + [
         (n, i32) for n in ("dtype", "act", "out_nchw_f32", "B", "Hi", "Wi", "C1", "C2", "Hq", "Wq", "sy", "sx", "T", "KW",
-                           "ty", "tx", "oy0", "ox0", "Ho", "Wo", "osy", "osx", "ooy", "oox", "N", "ldw", "ldc", "coff", "in2_batch")]
+                           "ty", "tx", "oy0", "ox0", "Ho", "Wo", "osy", "osx", "ooy", "oox", "N", "ldw", "ldc", "coff", "in2_batch",
+                           "reserved0")] + [("addend", vp)]
 
 
 class DmWgrad(C.Structure):

@@ -56,6 +56,7 @@ struct ConvP {
     int splits, kper;
     float* ws;
     int B2;                                      // batch of the second source (in2 is read at sample b % B2); == B unless broadcast
+    const char* addend;                          // optional tensor of the output's layout / dtype added after the activation (gradient of a forked tensor)
 };
 
 // raw accumulators of one 128 x BN tile as they sit in the registers: [tile][wave][nt][mt][lane] float4 (1 KiB per store)
@@ -177,6 +178,33 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 
     }
 
     const bool vec_ok = ((p.ldc | p.coff) & 3) == 0 && !p.out_nchw;
+    int act = p.act;
+    if (p.addend) {                                        // out = act(z) + addend: the other consumer's gradient of a tensor used twice
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            if (!m_ok[mt]) continue;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int nb4 = n0 + wn * (BN / 2) + nt * 16 + fg * 4;
+                const T* a = (const T*)p.addend + orow[mt] * p.ldc + p.coff + nb4;
+                if (vec_ok && nb4 + 3 < p.N) {
+                    if constexpr (sizeof(T) == 4) {
+                        const f32x4 q = *(const f32x4*)a;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[nt][mt][r] = act_apply_t<T>(acc[nt][mt][r], act) + q[r];
+                    } else {
+                        const typename V16<T>::x4 q = *(const typename V16<T>::x4*)a;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[nt][mt][r] = act_apply_t<T>(acc[nt][mt][r], act) + (float)q[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[nt][mt][r] = act_apply_t<T>(acc[nt][mt][r], act) + (nb4 + r < p.N ? Elem<T>::ld(a + r) : 0.f);
+                }
+            }
+        }
+        act = DM_ACT_NONE;
+    }
     if constexpr (sizeof(T) == 2 && NT % 2 == 0) {
         // bf16 NHWC, both 16-channel blocks of a pair inside N and 16-byte aligned: a lane holds 4 channels (8 B) of blocks a and b;
         // one v_permlane16_swap per dword trades block b of the even 16-lane rows for block a of the odd rows, so that every lane
@@ -192,8 +220,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         typedef typename V16<T>::x2 t2;
-                        const t2 a2 = {(T)act_apply_t<T>(acc[2 * pr][mt][2 * h], p.act), (T)act_apply_t<T>(acc[2 * pr][mt][2 * h + 1], p.act)};
-                        const t2 b2 = {(T)act_apply_t<T>(acc[2 * pr + 1][mt][2 * h], p.act), (T)act_apply_t<T>(acc[2 * pr + 1][mt][2 * h + 1], p.act)};
+                        const t2 a2 = {(T)act_apply_t<T>(acc[2 * pr][mt][2 * h], act), (T)act_apply_t<T>(acc[2 * pr][mt][2 * h + 1], act)};
+                        const t2 b2 = {(T)act_apply_t<T>(acc[2 * pr + 1][mt][2 * h], act), (T)act_apply_t<T>(acc[2 * pr + 1][mt][2 * h + 1], act)};
                         const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a2), __builtin_bit_cast(unsigned, b2), false, false);
                         qa[h] = sw[0];                     // even rows: own a      | odd rows: partner's b
                         qb[h] = sw[1];                     // even rows: partner's a | odd rows: own b
@@ -217,7 +245,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 
             if (nb4 >= p.N) continue;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = act_apply_t<T>(acc[nt][mt][r], p.act);
+            for (int r = 0; r < 4; ++r) v[r] = act_apply_t<T>(acc[nt][mt][r], act);
             if (p.out_nchw) {
                 float* o = (float*)p.out;
 #pragma unroll
@@ -877,6 +905,8 @@ extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
     p.N = d->N; p.ldw = d->ldw; p.ldc = d->ldc; p.coff = d->coff; p.M = (int)M;
     p.splits = 1; p.kper = 1 << 24; p.ws = nullptr;
     p.B2 = d->in2_batch > 0 ? d->in2_batch : d->B;
+    p.addend = (const char*)d->addend;
+    DM_CHECK_ARG(d->addend == nullptr || !d->out_nchw_f32, "dm_conv: addend is not supported with the NCHW fp32 output");
     if (p.B2 != p.B) {                           // broadcast second source: the halo-resident kernel only
         DM_CHECK_ARG(d->C2 > 0 && d->B % p.B2 == 0, "dm_conv: in2_batch=%d must divide B=%d", p.B2, d->B);
         DM_CHECK_ARG(d->dtype != DM_F32 && g_variant >= 5 && halo_eligible(p),

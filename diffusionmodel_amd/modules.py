@@ -83,9 +83,9 @@ def _conv(cin, cout, k, stride=1, pad=0):
     return m
 
 
-def _strip_conv(x, conv):
+def _strip_conv(x, conv, fork=None):
     """1x1 conv on an fp32 strip (B, L, C) -> (B, L, C')."""
-    return ops.linear(x, conv.weight, conv.bias)
+    return ops.linear(x, conv.weight, conv.bias, fork)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -113,7 +113,8 @@ class CoordAttn(_HipBlock):
         B, H, W, C = x.shape
         if H != W:
             raise DmError("CoordAttn on the HIP path needs H == W (the reference's adaptive pools are then the identity)")
-        xh, xw = ops.PoolStrips.apply(x)                                           # :102-103
+        fx, fh, fw = ops.GradFork(), ops.GradFork(), ops.GradFork()      # x, xh, xw each feed two consumers
+        xh, xw = ops.PoolStrips.apply(x, fx)                                       # :102-103
         if not torch.is_grad_enabled() and not self.bn1_h.training and not self.bn1_w.training:
             # sampler: running-statistics BatchNorm folded into the dense weights, GELU in the epilogue (:105-111 in one launch each)
             wh, bh = ops.folded_dense_bn(self.conv1_h, self._sp_h)
@@ -123,13 +124,13 @@ class CoordAttn(_HipBlock):
         else:
             xh = ops.BnActMatrix.apply(_strip_conv(xh, self.conv1_h), self.bn1_h.weight, self.bn1_h.bias, self.bn1_h, self._sp_h, ACT_GELU)
             xw = ops.BnActMatrix.apply(_strip_conv(xw, self.conv1_w), self.bn1_w.weight, self.bn1_w.bias, self.bn1_w, self._sp_w, ACT_GELU)
-        h2w = _strip_conv(xh, self.h2w_proj)                                       # :113
-        w2h = _strip_conv(xw, self.w2h_proj)                                       # :114
-        xh = ops.SigMix.apply(xh, w2h, self.gamma_h)                               # :125
-        xw = ops.SigMix.apply(xw, h2w, self.gamma_w)                               # :126
+        h2w = _strip_conv(xh, self.h2w_proj, fh)                                   # :113
+        w2h = _strip_conv(xw, self.w2h_proj, fw)                                   # :114
+        xh = ops.SigMix.apply(fh.second(xh), w2h, self.gamma_h)                    # :125
+        xw = ops.SigMix.apply(fw.second(xw), h2w, self.gamma_w)                    # :126
         lh = _strip_conv(xh, self.conv_h)
         lw = _strip_conv(xw, self.conv_w)
-        return ops.CaGate.apply(x, lh, lw, self.alpha, self.beta)                  # :128-140
+        return ops.CaGate.apply(fx.second(x), lh, lw, self.alpha, self.beta)       # :128-140
 
     def forward(self, x):
         return self._nchw_call(x)
@@ -199,12 +200,17 @@ class ResConvBlock(_HipBlock):
     def _out_channels(self):
         return self.out_ch
 
-    def _fwd(self, x):
-        x1 = ops.conv_bn_act(x, None, self.conv1[0], self.conv1[1], self._sp1)
-        x2 = ops.conv_bn_act(x1, None, self.conv2[0], self.conv2[1], self._sp2)
+    def _fwd(self, x, fork=None):
+        """`fork`: x also feeds a later consumer outside the block (a skip connection); its gradient joins in conv1's input gradient."""
         if not self.is_res:
-            return x2
-        res = x if self.same_ch else x1
+            x1 = ops.conv_bn_act(x, None, self.conv1[0], self.conv1[1], self._sp1, fork)
+            return ops.conv_bn_act(x1, None, self.conv2[0], self.conv2[1], self._sp2)
+        if fork is not None:
+            raise DmError("ResConvBlock: a residual block forks its own input; an outer fork is not supported")
+        fr = ops.GradFork()                                   # the residual input (x, or x1 when the channel count changes) is used twice
+        x1 = ops.conv_bn_act(x, None, self.conv1[0], self.conv1[1], self._sp1, fr if self.same_ch else None)
+        x2 = ops.conv_bn_act(x1, None, self.conv2[0], self.conv2[1], self._sp2, None if self.same_ch else fr)
+        res = fr.second(x if self.same_ch else x1)
         if self._with_se:
             return ops.SeResidual.apply(x2, res, self.se.fc[0].weight, self.se.fc[2].weight, INV_1414, torch.is_grad_enabled())
         return ops.SeResidual.apply(x2, res, None, None, INV_1414)
@@ -238,8 +244,9 @@ class UnetDown(_HipBlock):
     def _out_channels(self):
         return self.out_ch
 
-    def _fwd(self, x):
-        x = ops.conv_bn_act(x, None, self.channel_compress[0], self.channel_compress[1], self._sp_cc)
+    def _fwd(self, x, fork=None):
+        """`fork`: x is also a skip tensor (consumed again by the decoder)."""
+        x = ops.conv_bn_act(x, None, self.channel_compress[0], self.channel_compress[1], self._sp_cc, fork)
         x = ops.conv_bn_act(x, None, self.ch_adjust, None, self._sp_adj)
         x = ops.conv_bn_act(x, None, self.down[0], self.down[1], self._sp_d0)
         x = self.down[3]._fwd(x)
@@ -331,18 +338,21 @@ class ContextUnet(_HipBlock):
 
     def _encode(self, x8):
         """Same, from an NHWC tensor already in the compute dtype (channels padded to 8)."""
+        # every skip tensor feeds the next encoder stage now and the decoder later: the decoder's gradient is stashed (GradFork)
+        # and added by the encoder stage's first input-gradient kernel instead of by an elementwise pass of autograd's
+        f0, f1, f2, f3, f4 = (ops.GradFork() for _ in range(5))
         x0 = self.init_conv._fwd(x8)
-        d1 = self.ca1._fwd(self.down1._fwd(x0))
-        d2 = self.ca2._fwd(self.down2._fwd(d1))
-        d3 = self.ca3._fwd(self.down3._fwd(d2))
-        d4 = self.ca4._fwd(self.down4._fwd(d3))
+        d1 = self.ca1._fwd(self.down1._fwd(x0, f0))
+        d2 = self.ca2._fwd(self.down2._fwd(d1, f1))
+        d3 = self.ca3._fwd(self.down3._fwd(d2, f2))
+        d4 = self.ca4._fwd(self.down4._fwd(d3, f3))
         if d4.shape[1] < self.bottleneck_k or d4.shape[2] < self.bottleneck_k:
             raise DmError(f"input {tuple(x8.shape[1:3])} is too small for bottleneck_k={self.bottleneck_k}: "
                           "four stride-2 stages then AvgPool(k) (the reference fails the same way; use bottleneck_k=4 for 64x64)")
-        hidden = ops.AvgPoolGelu.apply(d4, self.bottleneck_k)                                           # :332
+        hidden = ops.AvgPoolGelu.apply(d4, self.bottleneck_k, f4)                                       # :332
         u1 = ops.ConvTransposeKS.apply(hidden, self.up0[0].weight, self.up0[0].bias, self.compute_dtype)
         u1 = ops.GroupNormAct.apply(u1, self.up0[1].weight, self.up0[1].bias, 8, ACT_RELU)            # :297-301
-        return x0, d1, d2, d3, d4, u1
+        return f0.second(x0), f1.second(d1), f2.second(d2), f3.second(d3), f4.second(d4), u1
 
     def embed(self, c, t, ctx_mask):
         oh = ops.onehot_mask(c.long(), ctx_mask.float(), self.n_classes)                                # :334-340

@@ -63,8 +63,10 @@ class _ZeroArena:
                 return torch.zeros(shape, dtype=torch.float32, device=ref.device)
             self.buf, self.off = torch.zeros(self.CAP // 4, dtype=torch.float32, device=ref.device), 0
         lo = (self.off + 3) // 4 * 4                  # 16-byte aligned slices
-        if lo + n > self.buf.numel() or torch.cuda.is_current_stream_capturing():
+        if lo + n > self.buf.numel():
             return torch.zeros(shape, dtype=torch.float32, device=ref.device)
+        # (also inside a stream capture: the arena is a static buffer, the slices are handed out in the same order on every
+        #  replay and recycle()'s one fill is captured with them — the fallback would put ~130 fill launches into every step)
         self.off = lo + n
         return self.buf[lo:lo + n].view(shape)
 
@@ -84,6 +86,41 @@ def _gzeros(shape, ref):
     if ARENA_ENABLED[0]:
         return ZERO_ARENA.take(shape, ref)
     return torch.zeros(shape, dtype=torch.float32, device=ref.device)
+
+
+class GradFork:
+    """A tensor with TWO consumers (the skip / residual / attention forks of new_scripy.py:196-205, 242, 320-355).  autograd would
+    add the two gradients with an elementwise kernel of its own; instead the LATER consumer (which runs its backward FIRST — in
+    every fork of this network it also consumes something computed from the earlier consumer's output) leaves its gradient here
+    (`second(x)`), and the earlier consumer's input-gradient kernel adds it in its epilogue (`take()` -> DmConv.addend / the
+    `dout_gate` operand of dm_ca_pool_bwd / dm_add)."""
+    __slots__ = ("stash",)
+
+    def __init__(self):
+        self.stash = None
+
+    def second(self, x):
+        """The later consumer reads x through this: identity forward, the gradient is stashed instead of returned."""
+        self.stash = None
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _StashGrad.apply(x, self)
+        return x
+
+    def take(self):
+        g, self.stash = self.stash, None
+        return g
+
+
+class _StashGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, fork):
+        ctx.fork = fork
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.fork.stash = g.contiguous()
+        return None, None
 
 
 def _cl(w):
@@ -227,7 +264,7 @@ def _desc_cache():
 
 def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0,
                Ho, Wo, N, osy=1, osx=1, ooy=0, oox=0, ldc=None, coff=0, scale=None, shift=None, act=ACT_NONE,
-               psum=None, psq=None, out_nchw=False, in2_batch=0):
+               psum=None, psq=None, out_nchw=False, in2_batch=0, addend=None):
     L.ensure_workspace()          # split-K partial tiles of small, deep problems
     # the geometry half of the descriptor is the same every step: one ctypes struct per distinct call, only the eight pointers
     # change (filling 37 fields costs ~6 us of Python per launch; the backward pass runs on autograd's thread, hence per thread)
@@ -247,6 +284,7 @@ def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, s
         cache[key] = d
     d.in1, d.in2, d.w = ptr(in1), ptr(in2), w_ptr
     d.scale, d.shift, d.out, d.psum, d.psq = ptr(scale), ptr(shift), ptr(out), ptr(psum), ptr(psq)
+    d.addend = ptr(addend)
     kind = "conv_igemm" if dtype != torch.float32 else "igemm_f32"
     if PROFILE_META is not None:
         call("dm_conv", C.byref(d))
@@ -369,8 +407,9 @@ class ConvBnAct(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, x2, w, b, gamma, beta, spec, need_grad=True):
+    def forward(ctx, x, x2, w, b, gamma, beta, spec, need_grad=True, fork=None):
         L.require_device(x, w)
+        ctx.fork = fork                                        # GradFork of x: another consumer's gradient of x is added in the dgrad epilogue
         x = x.contiguous()
         x2 = x2.contiguous() if x2 is not None else None
         B, Hi, Wi, C1 = x.shape
@@ -474,11 +513,15 @@ class ConvBnAct(torch.autograd.Function):
         if needs[0] or (x2 is not None and needs[1]):
             targets = [(0, C1, needs[0])] + ([(C1, C2, needs[1])] if x2 is not None else [])
             outs = []
+            stash = ctx.fork.take() if ctx.fork is not None else None
+            if stash is not None and (not needs[0] or tuple(stash.shape) != (B, Hi, Wi, C1) or stash.dtype != dtype):
+                raise L.DmError("conv backward: the stashed gradient of the forked input does not match it")
             for (c_lo, c_n, need) in targets:
                 if not need:
                     outs.append(None)
                     continue
                 dxi = _empty((B, Hi, Wi, c_n), dtype, g)
+                add_i = stash if c_lo == 0 else None
                 if (kh % s) or (kw % s):
                     raise L.DmError("conv backward: kernel size must be a multiple of the stride")
                 if c_lo + c_n > Cin:       # padded stem input: its gradient is never needed
@@ -495,7 +538,7 @@ class ConvBnAct(torch.autograd.Function):
                         _conv_call(dz, None, wt.data_ptr() + c_lo * row_bytes, len(taps) * ldy, dxi, dtype=dtype, B=B, Hi=Ho, Wi=Wo,
                                    C1=ldy, C2=0, Hq=Hi // s, Wq=Wi // s, sy=1, sx=1, T=len(taps), KW=kw // s, ty=-1, tx=-1,
                                    oy0=(py + p - ky0) // s, ox0=(px + p - kx0) // s, Ho=Hi, Wo=Wi, osy=s, osx=s, ooy=py, oox=px,
-                                   N=c_n)
+                                   N=c_n, addend=add_i)
                 outs.append(dxi)
             dx = outs[0]
             dx2 = outs[1] if x2 is not None else None
@@ -526,16 +569,16 @@ class ConvBnAct(torch.autograd.Function):
                     tgt = _empty((N, kh, kw, Cin), torch.float32, g)
                     call("dm_unpad_dw", ptr(tmp), ptr(tgt), N, T, Cin, Cp, 0)
                     dw = tgt.permute(0, 3, 1, 2)
-        return dx, dx2, dw, db, dgamma, dbeta, None, None
+        return dx, dx2, dw, db, dgamma, dbeta, None, None, None
 
 
-def conv_bn_act(x, x2, conv, bn, spec):
+def conv_bn_act(x, x2, conv, bn, spec, fork=None):
     """conv: holder with .weight/.bias (nn.Conv2d); bn: nn.BatchNorm2d holder or None."""
     gamma = bn.weight if bn is not None else None
     beta = bn.bias if bn is not None else None
     need_grad = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in (x, x2, conv.weight, conv.bias, gamma, beta))
-    return ConvBnAct.apply(x, x2, conv.weight, conv.bias, gamma, beta, spec, need_grad)
+    return ConvBnAct.apply(x, x2, conv.weight, conv.bias, gamma, beta, spec, need_grad, fork)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -666,7 +709,8 @@ def _lin_bwd(x, w, g, dx, dw, db):
 
 class Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, fork=None):
+        ctx.fork = fork
         L.require_device(x, w)
         x, w = x.contiguous(), w.contiguous()
         y = _empty((x.shape[0], w.shape[0]), torch.float32, x)
@@ -685,7 +729,10 @@ class Linear(torch.autograd.Function):
         dw = _gzeros((N, K), x) if ctx.needs_input_grad[1] else None
         db = _gzeros((N,), x) if (ctx.has_b and ctx.needs_input_grad[2]) else None
         _lin_bwd(x, w, g, dx, dw, db)
-        return dx, dw, db
+        stash = ctx.fork.take() if ctx.fork is not None else None
+        if stash is not None and dx is not None:
+            call("dm_add", ptr(dx), ptr(stash.reshape(dx.shape).contiguous()), ptr(dx), L.DM_F32, dx.numel())
+        return dx, dw, db, None
 
 
 def linear_act(x, w, b, act):
@@ -697,11 +744,11 @@ def linear_act(x, w, b, act):
     return y
 
 
-def linear(x, w, b=None):
+def linear(x, w, b=None, fork=None):
     """x (..., K) fp32 -> (..., N); w may be a 1x1-conv weight (N, K, 1, 1)."""
     w2 = w.reshape(w.shape[0], -1) if w.dim() == 4 else w
     lead = x.shape[:-1]
-    y = Linear.apply(x.reshape(-1, x.shape[-1]), w2, b)
+    y = Linear.apply(x.reshape(-1, x.shape[-1]), w2, b, fork)
     return y.reshape(*lead, w2.shape[0])
 
 
@@ -830,7 +877,8 @@ class SeResidual(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 class PoolStrips(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, fork=None):
+        ctx.fork = fork
         L.require_device(x)
         x = x.contiguous()
         B, H, W, Cc = x.shape
@@ -844,8 +892,9 @@ class PoolStrips(torch.autograd.Function):
         shape, dtype = ctx.meta
         B, H, W, Cc = shape
         dx = _empty(shape, dtype, gh)
-        call("dm_ca_pool_bwd", ptr(gh.contiguous()), ptr(gw.contiguous()), None, ptr(dx), dt(dtype), B, H, W, Cc)
-        return dx
+        stash = ctx.fork.take() if ctx.fork is not None else None      # CaGate's gradient of x (new_scripy.py:138-140), added in the same pass
+        call("dm_ca_pool_bwd", ptr(gh.contiguous()), ptr(gw.contiguous()), ptr(stash), ptr(dx), dt(dtype), B, H, W, Cc)
+        return dx, None
 
 
 class SigMix(torch.autograd.Function):
@@ -972,7 +1021,8 @@ class AvgPoolGelu(torch.autograd.Function):
     """AvgPool2d(k) + GELU -> fp32 (new_scripy.py:290)"""
 
     @staticmethod
-    def forward(ctx, x, k):
+    def forward(ctx, x, k, fork=None):
+        ctx.fork = fork
         x = x.contiguous()
         B, H, W, Cc = x.shape
         y = _empty((B, H // k, W // k, Cc), torch.float32, x)
@@ -989,7 +1039,10 @@ class AvgPoolGelu(torch.autograd.Function):
             raise L.DmError("avgpool backward needs H, W divisible by k")
         dx = _empty(x.shape, x.dtype, x)
         call("dm_avgpool_gelu_bwd", ptr(x), ptr(g.contiguous()), ptr(dx), dt(x), B, H, W, Cc, ctx.k)
-        return dx, None
+        stash = ctx.fork.take() if ctx.fork is not None else None
+        if stash is not None:
+            call("dm_add", ptr(dx), ptr(stash), ptr(dx), dt(x), dx.numel())
+        return dx, None, None
 
 
 class MaxPool2(torch.autograd.Function):

@@ -58,6 +58,11 @@ typedef struct DmConv {
     int32_t in2_batch;                            /* 0 or B: in2 has B samples.  n < B (n | B): in2 has n samples and sample b reads
                                                      b % n — the CFG sampler's doubled batch over a skip tensor computed once
                                                      (halo-resident 3x3 kernel only) */
+    int32_t reserved0;                            /* 0 */
+    const void* addend;                           /* NULL, or a tensor of the output's layout and dtype: out = act(...) + addend.  The
+                                                     input-gradient launch of a layer whose input feeds a second consumer adds that
+                                                     consumer's gradient here instead of a separate elementwise pass (autograd's
+                                                     accumulation of new_scripy.py's skip / residual tensors) */
 } DmConv;
 int dm_conv(const DmConv* d, dm_stream_t stream);
 /* tuning knob: staging pipeline of dm_conv — 1 = register staging, 2..4 = LDS-DMA gather ring with that many stages,
