@@ -23,7 +23,7 @@ class DmConv(C.Structure):
     _fields_ = [(n, vp) for n in ("in1", "in2", "w", "scale", "shift", "out", "psum", "psq")] + [
         (n, i32) for n in ("dtype", "act", "out_nchw_f32", "B", "Hi", "Wi", "C1", "C2", "Hq", "Wq", "sy", "sx", "T", "KW",
                            "ty", "tx", "oy0", "ox0", "Ho", "Wo", "osy", "osx", "ooy", "oox", "N", "ldw", "ldc", "coff", "in2_batch",
-                           "reserved0")] + [("addend", vp)]
+                           "stat_slots")] + [("addend", vp)]
 
 
 class DmWgrad(C.Structure):
@@ -47,6 +47,9 @@ _PROTOS = {
     "dm_col_reduce2": [vp, vp, i32, i32, vp, vp],
     "dm_bn_act_bwd_apply": [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp],
     "dm_bn_fold": [vp, vp, vp, vp, vp, f32, i32, vp, vp],
+    "dm_bn_act_fwd_slots": [vp, vp, i32, i32, i32, vp, vp, i32, f32, f32, vp, vp, i32, vp, vp, vp, vp],
+    "dm_bn_act_bwd_reduce_slots": [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32],
+    "dm_bn_act_bwd_apply_slots": [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp],
     "dm_gn_act_fwd": [vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp],
     "dm_gn_act_bwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp],
     "dm_pool_hw": [vp, i32, i32, i32, i32, vp],

@@ -56,6 +56,7 @@ struct ConvP {
     int splits, kper;
     float* ws;
     int B2;                                      // batch of the second source (in2 is read at sample b % B2); == B unless broadcast
+    int stat_slots;                              // 0: psum / psq are [tiles][N] partial rows; S > 0: [S][N] accumulators, tile mb adds into slot mb % S
     const char* addend;                          // optional tensor of the output's layout / dtype added after the activation (gradient of a forked tensor)
 };
 
@@ -172,8 +173,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 
             }
         __syncthreads();
         if (tid < BN && n0 + tid < p.N) {
-            p.psum[(size_t)mb * p.N + n0 + tid] = sred[0 * BN + tid] + sred[2 * BN + tid];
-            p.psq[(size_t)mb * p.N + n0 + tid] = sred[1 * BN + tid] + sred[3 * BN + tid];
+            if (p.stat_slots > 0) {                        // a few slots the consuming kernel folds itself (no finalize launch)
+                // fp64 accumulators: precision of the old fp64 fold over the partial rows, and the arrival order moves nothing visible
+                atomicAdd((double*)p.psum + (size_t)(mb % p.stat_slots) * p.N + n0 + tid, (double)(sred[0 * BN + tid] + sred[2 * BN + tid]));
+                atomicAdd((double*)p.psq + (size_t)(mb % p.stat_slots) * p.N + n0 + tid, (double)(sred[1 * BN + tid] + sred[3 * BN + tid]));
+            } else {
+                p.psum[(size_t)mb * p.N + n0 + tid] = sred[0 * BN + tid] + sred[2 * BN + tid];
+                p.psq[(size_t)mb * p.N + n0 + tid] = sred[1 * BN + tid] + sred[3 * BN + tid];
+            }
         }
     }
 
@@ -906,6 +913,9 @@ extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
     p.splits = 1; p.kper = 1 << 24; p.ws = nullptr;
     p.B2 = d->in2_batch > 0 ? d->in2_batch : d->B;
     p.addend = (const char*)d->addend;
+    p.stat_slots = d->stat_slots;
+    DM_CHECK_ARG(d->stat_slots >= 0 && d->stat_slots <= 64 && (d->stat_slots == 0 || (d->psum && (((uintptr_t)d->psum | (uintptr_t)d->psq) & 7) == 0)),
+                 "dm_conv: stat_slots=%d needs 8-byte aligned psum / psq (and must be <= 64)", d->stat_slots);
     DM_CHECK_ARG(d->addend == nullptr || !d->out_nchw_f32, "dm_conv: addend is not supported with the NCHW fp32 output");
     if (p.B2 != p.B) {                           // broadcast second source: the halo-resident kernel only
         DM_CHECK_ARG(d->C2 > 0 && d->B % p.B2 == 0, "dm_conv: in2_batch=%d must divide B=%d", p.B2, d->B);

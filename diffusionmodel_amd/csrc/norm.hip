@@ -14,7 +14,7 @@ namespace {
 //    row(r, col0, v1[V], v2[V]) produces the two quantities to sum.
 // ---------------------------------------------------------------------------------------------
 template <int V, typename F>
-__device__ inline void col_partial(int M, int C, int rows_per_block, float* p1, float* p2, F& f) {
+__device__ inline void col_partial(int M, int C, int rows_per_block, float* p1, float* p2, F& f, int slots = 0) {
     __shared__ float red[2][2048];
     const int CVt = (C + V - 1) / V;  // column vectors in total
     const int r0 = blockIdx.x * rows_per_block;
@@ -52,8 +52,14 @@ __device__ inline void col_partial(int M, int C, int rows_per_block, float* p1, 
             for (int l = 0; l < RL; ++l) { s1 += red[0][l * ncv * V + j]; s2 += red[1][l * ncv * V + j]; }
             const int col = cbase * V + j;
             if (col < C) {
-                p1[(size_t)blockIdx.x * C + col] = s1;
-                p2[(size_t)blockIdx.x * C + col] = s2;
+                if (slots > 0) {                       // [slots][C] fp64 accumulators (zeroed by the caller): the consumer folds the few slots itself;
+                                                       // fp64 atomics: the order of arrival then moves the sums by ~1e-16, i.e. not at all in fp32
+                    atomicAdd((double*)p1 + (size_t)(blockIdx.x % slots) * C + col, (double)s1);
+                    atomicAdd((double*)p2 + (size_t)(blockIdx.x % slots) * C + col, (double)s2);
+                } else {
+                    p1[(size_t)blockIdx.x * C + col] = s1;
+                    p2[(size_t)blockIdx.x * C + col] = s2;
+                }
             }
         }
         __syncthreads();
@@ -207,6 +213,51 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* z, T* y, int64
     }
 }
 
+// bn_act_fwd with the statistics folded in: psum / psq are [S][C] slot accumulators the producing convolution's epilogue added its
+// per-tile column sums into (DmConv.stat_slots).  Every workgroup folds the S slots of all C channels into LDS (S * C * 8 bytes from
+// L2 — S = 8: 8 KiB at C = 128) instead of a separate finalize launch; workgroup 0 also publishes mean / rstd (the backward pass
+// needs them) and updates the running statistics (nn.BatchNorm2d: momentum, unbiased variance).
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_act_fwd_slots_kernel(const T* z, T* y, int64_t nvec, int CV, const double* psum, const double* psq,
+                                                               int S, int M, float eps, float mom, const float* gamma, const float* beta,
+                                                               int act, float* mean_out, float* rstd_out, float* rmean, float* rvar) {
+    extern __shared__ float sstat[];                   // [2][C]
+    const int C = CV * V;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < S; ++k) { s1 += psum[(size_t)k * C + c]; s2 += psq[(size_t)k * C + c]; }
+        const double mu = s1 / M;
+        double var = s2 / M - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float rs = (float)(1.0 / sqrt(var + (double)eps));
+        sstat[c] = (float)mu;
+        sstat[C + c] = rs;
+        if (blockIdx.x == 0) {
+            mean_out[c] = (float)mu;
+            rstd_out[c] = rs;
+            if (rmean) {
+                const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+                rmean[c] = (float)((1.0 - mom) * (double)rmean[c] + mom * mu);
+                rvar[c] = (float)((1.0 - mom) * (double)rvar[c] + mom * unb);
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t G = ((int64_t)gridDim.x * 256 / CV) * CV;
+    const int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g0 >= G) return;
+    BnParams<V> P;
+    P.load((int)(g0 % CV) * V, C, sstat, sstat + C, gamma, beta);
+#pragma unroll 2
+    for (int64_t i = g0; i < nvec; i += G) {
+        float v[V];
+        load_cols<T, V>(z + i * V, v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) v[k] = act_apply_t<T>((v[k] - P.mu[k]) * P.rs[k] * P.gm[k] + P.bt[k], act);
+        store_cols<T, V>(y + i * V, v);
+    }
+}
+
 template <typename T, int V>
 struct BwdRedF {
     const T* z; const T* dy; int C; const float* mean; const float* rstd; const float* gamma; const float* beta; int act;
@@ -228,9 +279,9 @@ struct BwdRedF {
 template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* z, const T* dy, int M, int C, const float* mean,
                                                             const float* rstd, const float* gamma, const float* beta,
-                                                            int act, int rpb, float* p1, float* p2) {
+                                                            int act, int rpb, float* p1, float* p2, int slots) {
     BwdRedF<T, V> f{z, dy, C, mean, rstd, gamma, beta, act, {}};
-    col_partial<V>(M, C, rpb, p1, p2, f);
+    col_partial<V>(M, C, rpb, p1, p2, f, slots);
 }
 
 template <typename T, int V>
@@ -246,6 +297,46 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* z, const T* 
     float m1[V], m2[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) { m1[k] = s1[c0 + k] * invM; m2[k] = s2[c0 + k] * invM; }
+#pragma unroll 2
+    for (int64_t i = g0; i < nvec; i += G) {
+        float zz[V], dd[V];
+        load_cols<T, V>(z + i * V, zz);
+        load_cols<T, V>(dy + i * V, dd);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float xh = (zz[k] - P.mu[k]) * P.rs[k];
+            const float g = dd[k] * act_grad_t<T>(xh * P.gm[k] + P.bt[k], act);
+            zz[k] = P.gm[k] * P.rs[k] * (g - m1[k] - xh * m2[k]);
+        }
+        store_cols<T, V>(dz + i * V, zz);
+    }
+}
+
+// bn_bwd_apply with the column sums folded in: p1 / p2 are the [S][C] slot accumulators of bn_bwd_reduce_kernel (slots mode);
+// workgroup 0 publishes dbeta = sum(g), dgamma = sum(g * xhat) — the parameter gradients — instead of a separate reduce launch.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_bwd_apply_slots_kernel(const T* z, const T* dy, T* dz, int64_t nvec, int CV, float invM,
+                                                                 const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                                                 int act, const double* p1, const double* p2, int S, float* dbeta, float* dgamma) {
+    extern __shared__ float ssum[];                    // [2][C]
+    const int C = CV * V;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < S; ++k) { a += p1[(size_t)k * C + c]; b += p2[(size_t)k * C + c]; }
+        ssum[c] = (float)a;
+        ssum[C + c] = (float)b;
+        if (blockIdx.x == 0) { dbeta[c] = (float)a; dgamma[c] = (float)b; }
+    }
+    __syncthreads();
+    const int64_t G = ((int64_t)gridDim.x * 256 / CV) * CV;
+    const int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g0 >= G) return;
+    const int c0 = (int)(g0 % CV) * V;
+    BnParams<V> P;
+    P.load(c0, C, mean, rstd, gamma, beta);
+    float m1[V], m2[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { m1[k] = ssum[c0 + k] * invM; m2[k] = ssum[C + c0 + k] * invM; }
 #pragma unroll 2
     for (int64_t i = g0; i < nvec; i += G) {
         float zz[V], dd[V];
@@ -676,8 +767,8 @@ extern "C" int dm_bn_act_bwd_reduce(const void* z, const void* dy, int dtype, in
     DM_CHECK_ARG(z && dy && mean && rstd && p1 && p2 && M > 0 && C > 0, "dm_bn_act_bwd_reduce: bad arguments");
     const int rpb = cs_rows(M), grid = cdiv(M, rpb);
     DM_DISPATCH_DTYPE(dtype, {
-        if (vec_ok<T>(C, z, dy)) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, Elem<T>::VE>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2);
-        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2);
+        if (vec_ok<T>(C, z, dy)) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, Elem<T>::VE>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2, 0);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2, 0);
     });
     DM_LAUNCH_CHECK();
     return DM_OK;
@@ -697,6 +788,57 @@ extern "C" int dm_bn_act_bwd_apply(const void* z, const void* dy, void* dz, int 
             const int64_t nvec = (int64_t)M * C;
             hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), dim3(stream_grid(nvec, C)), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, (T*)dz, nvec, C, invM, mean, rstd, gamma, beta, act, s1, s2);
         }
+    });
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+/* ---- slot-folded statistics: no finalize / column-reduce launches between the producing and the consuming kernel ---- */
+extern "C" int dm_bn_act_fwd_slots(const void* z, void* y, int dtype, int M, int C, const void* psum, const void* psq, int slots, float eps,
+                                   float momentum, const float* gamma, const float* beta, int act, float* mean, float* rstd,
+                                   float* running_mean, float* running_var, dm_stream_t s) {
+    DM_CHECK_ARG(z && y && psum && psq && mean && rstd && M > 0 && C > 0 && slots > 0 && slots <= 64, "dm_bn_act_fwd_slots: bad arguments");
+    DM_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "dm_bn_act_fwd_slots: running_mean/var must come together");
+    DM_CHECK_ARG(C <= 8192, "dm_bn_act_fwd_slots: C=%d > 8192 (the statistics of all channels sit in LDS)", C);
+    DM_DISPATCH_DTYPE(dtype, {
+        DM_CHECK_ARG(vec_ok<T>(C, z, y), "dm_bn_act_fwd_slots: C=%d must be a multiple of %d and the tensors 16-byte aligned", C, Elem<T>::VE);
+        constexpr int V = Elem<T>::VE;
+        const int64_t nvec = (int64_t)M * C / V;
+        hipLaunchKernelGGL((bn_act_fwd_slots_kernel<T, V>), dim3(stream_grid(nvec, C / V)), dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const T*)z, (T*)y,
+                           nvec, C / V, (const double*)psum, (const double*)psq, slots, M, eps, momentum, gamma, beta, act, mean, rstd, running_mean, running_var);
+    });
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_bn_act_bwd_reduce_slots(const void* z, const void* dy, int dtype, int M, int C, const float* mean, const float* rstd,
+                                          const float* gamma, const float* beta, int act, void* p1v, void* p2v, int slots, dm_stream_t s) {
+    float* p1 = (float*)p1v;
+    float* p2 = (float*)p2v;
+    DM_CHECK_ARG(z && dy && mean && rstd && p1 && p2 && M > 0 && C > 0 && slots > 0 && slots <= 64 && (((uintptr_t)p1 | (uintptr_t)p2) & 7) == 0,
+                 "dm_bn_act_bwd_reduce_slots: bad arguments");
+    const int rpb = cs_rows(M), grid = cdiv(M, rpb);
+    DM_DISPATCH_DTYPE(dtype, {
+        if (vec_ok<T>(C, z, dy)) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, Elem<T>::VE>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2, slots);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2, slots);
+    });
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_bn_act_bwd_apply_slots(const void* z, const void* dy, void* dz, int dtype, int M, int C, const float* mean, const float* rstd,
+                                         const float* gamma, const float* beta, int act, const void* p1, const void* p2, int slots,
+                                         float* dbeta, float* dgamma, dm_stream_t s) {
+    DM_CHECK_ARG(z && dy && dz && mean && rstd && p1 && p2 && dbeta && dgamma && M > 0 && C > 0 && slots > 0 && slots <= 64,
+                 "dm_bn_act_bwd_apply_slots: bad arguments");
+    DM_CHECK_ARG(C <= 8192, "dm_bn_act_bwd_apply_slots: C=%d > 8192", C);
+    const float invM = 1.0f / (float)M;
+    DM_DISPATCH_DTYPE(dtype, {
+        DM_CHECK_ARG(vec_ok<T>(C, z, dy, dz), "dm_bn_act_bwd_apply_slots: C=%d must be a multiple of %d and the tensors 16-byte aligned", C, Elem<T>::VE);
+        constexpr int V = Elem<T>::VE;
+        const int64_t nvec = (int64_t)M * C / V;
+        hipLaunchKernelGGL((bn_bwd_apply_slots_kernel<T, V>), dim3(stream_grid(nvec, C / V)), dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const T*)z,
+                           (const T*)dy, (T*)dz, nvec, C / V, invM, mean, rstd, gamma, beta, act, (const double*)p1, (const double*)p2, slots, dbeta, dgamma);
     });
     DM_LAUNCH_CHECK();
     return DM_OK;

@@ -23,6 +23,7 @@ from . import _lib as L
 from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, call, dt, ptr
 
 BN_EPS = 1e-5
+BN_SLOTS = 8          # train-mode BatchNorm statistics travel as [BN_SLOTS][C] accumulators folded by the consuming kernel (0: partial rows + finalize launches)
 _EPOCH = [0]          # bumped by the fused optimiser: invalidates packed-weight caches
 _CACHE = {}
 ON_WGRAD = None       # parallel.GradReducer: called with the parameter whose main_grad a weight-gradient launch just completed
@@ -204,7 +205,7 @@ def refresh_packs():
     if not _T_PACKS:
         return
     if not _T_TABLES:
-        ents, taps_rows, blocks = [], [], []
+        ents, taps_rows, blocks, live_keys, live_ptrs = [], [], [], [], []
         for k in list(_T_PACKS):
             wr, out, (n, t, c, taps, np_, dty) = _T_PACKS[k]
             w = wr()
@@ -212,6 +213,8 @@ def refresh_packs():
                 del _T_PACKS[k]
                 continue
             e = len(ents)
+            live_keys.append(k)
+            live_ptrs.append(w.data_ptr())
             sh = getattr(w, "_dm_shadow16", None)         # bf16 copy of the parameter kept current by the fused optimiser step
             if sh is not None and dty == dt(sh):          # 0x100 / 0x200: the source is the bf16 / fp16 shadow
                 ents.append((sh.data_ptr(), out.data_ptr(), n, t, c, len(taps), np_, dty | (0x100 if dty == L.DM_BF16 else 0x200)))
@@ -228,8 +231,8 @@ def refresh_packs():
         _T_TABLES["ents"] = torch.tensor(ents, dtype=torch.int64).to(dev)
         _T_TABLES["taps"] = torch.tensor(taps_rows, dtype=torch.int32).to(dev)
         _T_TABLES["blocks"] = torch.tensor(blocks, dtype=torch.int32).to(dev)
-        _T_TABLES["ptrs"] = [_T_PACKS[k][0]().data_ptr() for k in _T_PACKS]
-        _T_TABLES["keys"] = list(_T_PACKS)
+        _T_TABLES["ptrs"] = live_ptrs                     # (collected while the parameters were known to be alive: a garbage
+        _T_TABLES["keys"] = live_keys                     #  collection during the uploads above may retire another model's)
     # a parameter whose storage moved since the tables were built falls back to the lazy per-tensor path
     keys = _T_TABLES["keys"]
     for k, p0 in zip(keys, _T_TABLES["ptrs"]):
@@ -264,12 +267,12 @@ def _desc_cache():
 
 def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0,
                Ho, Wo, N, osy=1, osx=1, ooy=0, oox=0, ldc=None, coff=0, scale=None, shift=None, act=ACT_NONE,
-               psum=None, psq=None, out_nchw=False, in2_batch=0, addend=None):
+               psum=None, psq=None, out_nchw=False, in2_batch=0, addend=None, stat_slots=0):
     L.ensure_workspace()          # split-K partial tiles of small, deep problems
     # the geometry half of the descriptor is the same every step: one ctypes struct per distinct call, only the eight pointers
     # change (filling 37 fields costs ~6 us of Python per launch; the backward pass runs on autograd's thread, hence per thread)
     key = (dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0, Ho, Wo, N, osy, osx, ooy, oox, ldc, coff, act,
-           out_nchw, in2_batch, ldw)
+           out_nchw, in2_batch, ldw, stat_slots)
     cache = _desc_cache()
     d = cache.get(key)
     if d is None:
@@ -281,6 +284,7 @@ def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, s
         d.Ho, d.Wo, d.osy, d.osx, d.ooy, d.oox = Ho, Wo, osy, osx, ooy, oox
         d.N, d.ldw, d.ldc, d.coff = N, ldw, (N if ldc is None else ldc), coff
         d.in2_batch = in2_batch
+        d.stat_slots = stat_slots
         cache[key] = d
     d.in1, d.in2, d.w = ptr(in1), ptr(in2), w_ptr
     d.scale, d.shift, d.out, d.psum, d.psq = ptr(scale), ptr(shift), ptr(out), ptr(psum), ptr(psq)
@@ -455,19 +459,30 @@ class ConvBnAct(torch.autograd.Function):
             return out
         z = _empty((B, Ho, Wo, N), dtype, x)
         mean, rstd = _empty((N,), torch.float32, x), _empty((N,), torch.float32, x)
-        if train:
-            nblk = (M + 127) // 128
-            psum, psq = _empty((nblk, N), torch.float32, x), _empty((nblk, N), torch.float32, x)
-            _conv_call(x, x2, ptr(wp), T * Cp, z, shift=b, psum=psum, psq=psq, **geom)
-            call("dm_bn_finalize", ptr(psum), ptr(psq), nblk, M, N, BN_EPS, bn.momentum, ptr(mean), ptr(rstd),
-                 ptr(bn.running_mean), ptr(bn.running_var))
+        out = _empty((B, Ho, Wo, N), dtype, x)
+        slots = BN_SLOTS if (train and N % (4 if dtype == torch.float32 else 8) == 0 and N <= 8192) else 0
+        if train and slots:
+            # the conv epilogue adds its per-tile column sums into [slots][N] accumulators; the normalise + activation kernel folds
+            # them in its prologue (and updates the running statistics): no finalize launch in between
+            st = _gzeros((2, slots, 2 * N), x)               # [2][slots][N] doubles
+            _conv_call(x, x2, ptr(wp), T * Cp, z, shift=b, psum=st[0], psq=st[1], stat_slots=slots, **geom)
+            call("dm_bn_act_fwd_slots", ptr(z), ptr(out), dt(dtype), M, N, ptr(st[0]), ptr(st[1]), slots, BN_EPS, bn.momentum, ptr(gamma), ptr(beta),
+                 spec.act, ptr(mean), ptr(rstd), ptr(bn.running_mean), ptr(bn.running_var))
             spec.nbt_pending += 1
             bn._stat_epoch = getattr(bn, "_stat_epoch", 0) + 1
-        else:  # eval mode with autograd: normalise with the running statistics, unfused
-            _conv_call(x, x2, ptr(wp), T * Cp, z, shift=b, **geom)
-            mean, rstd = _running_stats(bn, N)
-        out = _empty((B, Ho, Wo, N), dtype, x)
-        call("dm_bn_act_fwd", ptr(z), ptr(out), dt(dtype), M, N, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), spec.act)
+        else:
+            if train:
+                nblk = (M + 127) // 128
+                psum, psq = _empty((nblk, N), torch.float32, x), _empty((nblk, N), torch.float32, x)
+                _conv_call(x, x2, ptr(wp), T * Cp, z, shift=b, psum=psum, psq=psq, **geom)
+                call("dm_bn_finalize", ptr(psum), ptr(psq), nblk, M, N, BN_EPS, bn.momentum, ptr(mean), ptr(rstd),
+                     ptr(bn.running_mean), ptr(bn.running_var))
+                spec.nbt_pending += 1
+                bn._stat_epoch = getattr(bn, "_stat_epoch", 0) + 1
+            else:  # eval mode with autograd: normalise with the running statistics, unfused
+                _conv_call(x, x2, ptr(wp), T * Cp, z, shift=b, **geom)
+                mean, rstd = _running_stats(bn, N)
+            call("dm_bn_act_fwd", ptr(z), ptr(out), dt(dtype), M, N, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), spec.act)
         ctx.train = train
         ctx.save_for_backward(x, x2, w, z, mean, rstd, gamma, beta)
         return out
@@ -483,19 +498,27 @@ class ConvBnAct(torch.autograd.Function):
         if ctx.has_bn:
             x, x2, w, z, mean, rstd, gamma, beta = ctx.saved_tensors
             g = g.contiguous()
-            nblk = L.colstat_blocks(M)
-            p1, p2 = _empty((nblk, N), torch.float32, g), _empty((nblk, N), torch.float32, g)
-            call("dm_bn_act_bwd_reduce", ptr(z), ptr(g), dt(dtype), M, N, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), spec.act,
-                 ptr(p1), ptr(p2))
             dbeta, dgamma = _empty((N,), torch.float32, g), _empty((N,), torch.float32, g)
-            call("dm_col_reduce2", ptr(p1), ptr(p2), nblk, N, ptr(dbeta), ptr(dgamma))
             dz = _empty(z.shape, dtype, g)
-            if ctx.train:
-                s1, s2 = dbeta, dgamma
+            slots = BN_SLOTS if (ctx.train and N % (4 if dtype == torch.float32 else 8) == 0 and N <= 8192) else 0
+            if slots:      # sums of g and g*xhat as [slots][N] accumulators folded by the apply kernel (which also emits dbeta / dgamma)
+                pp = _gzeros((2, slots, 2 * N), g)           # [2][slots][N] doubles
+                call("dm_bn_act_bwd_reduce_slots", ptr(z), ptr(g), dt(dtype), M, N, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), spec.act,
+                     ptr(pp[0]), ptr(pp[1]), slots)
+                call("dm_bn_act_bwd_apply_slots", ptr(z), ptr(g), ptr(dz), dt(dtype), M, N, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+                     spec.act, ptr(pp[0]), ptr(pp[1]), slots, ptr(dbeta), ptr(dgamma))
             else:
-                s1 = s2 = _gzeros((N,), g)
-            call("dm_bn_act_bwd_apply", ptr(z), ptr(g), ptr(dz), dt(dtype), M, N, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
-                 spec.act, ptr(s1), ptr(s2))
+                nblk = L.colstat_blocks(M)
+                p1, p2 = _empty((nblk, N), torch.float32, g), _empty((nblk, N), torch.float32, g)
+                call("dm_bn_act_bwd_reduce", ptr(z), ptr(g), dt(dtype), M, N, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), spec.act,
+                     ptr(p1), ptr(p2))
+                call("dm_col_reduce2", ptr(p1), ptr(p2), nblk, N, ptr(dbeta), ptr(dgamma))
+                if ctx.train:
+                    s1, s2 = dbeta, dgamma
+                else:
+                    s1 = s2 = _gzeros((N,), g)
+                call("dm_bn_act_bwd_apply", ptr(z), ptr(g), ptr(dz), dt(dtype), M, N, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+                     spec.act, ptr(s1), ptr(s2))
             ldy = N
         else:
             x, x2, w = ctx.saved_tensors

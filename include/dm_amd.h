@@ -48,7 +48,7 @@ typedef struct DmConv {
     const void* in1; const void* in2; const void* w;
     const float* scale; const float* shift;      /* per output channel, may be NULL (1 / 0) */
     void* out;                                    /* NHWC `dtype`, or NCHW fp32 when out_nchw_f32 */
-    float* psum; float* psq;                      /* NULL or [ceil(M/128)][N] */
+    float* psum; float* psq;                      /* NULL, [ceil(M/128)][N], or [stat_slots][N] (see stat_slots) */
     int32_t dtype, act, out_nchw_f32;
     int32_t B, Hi, Wi, C1, C2;
     int32_t Hq, Wq, sy, sx;
@@ -58,7 +58,9 @@ typedef struct DmConv {
     int32_t in2_batch;                            /* 0 or B: in2 has B samples.  n < B (n | B): in2 has n samples and sample b reads
                                                      b % n — the CFG sampler's doubled batch over a skip tensor computed once
                                                      (halo-resident 3x3 kernel only) */
-    int32_t reserved0;                            /* 0 */
+    int32_t stat_slots;                           /* 0: psum / psq are [ceil(M/128)][N] partial rows (dm_bn_finalize folds them).  S in 1..64: they are
+                                                     ZEROED [S][N] **double** accumulators, tile i adds its column sums into slot i % S with fp64
+                                                     atomics and dm_bn_act_fwd_slots folds the S slots itself — no finalize launch */
     const void* addend;                           /* NULL, or a tensor of the output's layout and dtype: out = act(...) + addend.  The
                                                      input-gradient launch of a layer whose input feeds a second consumer adds that
                                                      consumer's gradient here instead of a separate elementwise pass (autograd's
@@ -135,6 +137,18 @@ int dm_col_reduce2(const float* part1, const float* part2, int nblk, int C, floa
 int dm_bn_act_bwd_apply(const void* z, const void* dy, void* dz, int dtype, int M, int C, const float* mean,
                         const float* rstd, const float* gamma, const float* beta, int act,
                         const float* s1, const float* s2, dm_stream_t s);
+/* Slot-folded forms (train-mode BatchNorm, new_scripy.py:185-186 etc.): the statistics arrive as [slots][C] DOUBLE accumulators
+ * (DmConv.stat_slots / dm_bn_act_bwd_reduce_slots add into ZEROED buffers with fp64 atomics) and the consuming kernel folds them in its
+ * prologue; workgroup 0 publishes mean / rstd + running statistics (forward) or dbeta / dgamma (backward).  Per layer this removes the
+ * dm_bn_finalize and dm_col_reduce2 launches.  C % 8 == 0 (bf16 / fp16) or % 4 (fp32), C <= 8192. */
+int dm_bn_act_fwd_slots(const void* z, void* y, int dtype, int M, int C, const void* psum, const void* psq, int slots, float eps,
+                        float momentum, const float* gamma, const float* beta, int act, float* mean, float* rstd,
+                        float* running_mean, float* running_var, dm_stream_t s);
+int dm_bn_act_bwd_reduce_slots(const void* z, const void* dy, int dtype, int M, int C, const float* mean, const float* rstd,
+                               const float* gamma, const float* beta, int act, void* p1, void* p2, int slots, dm_stream_t s);
+int dm_bn_act_bwd_apply_slots(const void* z, const void* dy, void* dz, int dtype, int M, int C, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, int act, const void* p1, const void* p2, int slots,
+                              float* dbeta, float* dgamma, dm_stream_t s);
 /* eval-mode BN folded to per-channel scale/shift for dm_conv: scale = gamma*rsqrt(var+eps),
  * shift = (conv_bias - mean)*scale + beta  (conv_bias may be NULL) */
 int dm_bn_fold(const float* gamma, const float* beta, const float* rmean, const float* rvar, const float* conv_bias,
