@@ -46,6 +46,26 @@ __global__ void randn_kernel(float* out, int64_t n, uint64_t seed, uint64_t offs
     }
 }
 
+// The per-sample draws of DDPM.forward (new_scripy.py:405, 413): t ~ U{1..n_T} and the classifier-free-guidance keep mask
+// ~ Bernoulli(keep_prob), from the same Philox key as the noise with a counter range of their own (bit 62 of the low word), at the
+// stream offset held on the device — which this launch ADVANCES by one (one workgroup: every thread reads the offset, then thread 0
+// writes it back), so a replayed step (hipGraph or launch plan) draws fresh timesteps with no host involvement.  Also emits
+// t / n_T as the float the network is fed (:415, an fp32 true division like torch's).
+__global__ __launch_bounds__(256) void draw_ts_keep_kernel(int64_t* ts, float* tfrac, float* keep, int B, int n_T, float keep_prob, uint64_t seed,
+                                                           uint64_t* offset_dev) {
+    const uint64_t offset = *offset_dev + 1;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        const uint64_t lo = (1ull << 62) + (uint64_t)i;
+        const U4 r = philox4x32_10(U4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)}, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const int64_t t = 1 + (int64_t)(((uint64_t)r.x * (uint64_t)n_T) >> 32);
+        ts[i] = t;
+        tfrac[i] = (float)t / (float)n_T;
+        keep[i] = ((float)r.y * 2.3283064365386963e-10f) < keep_prob ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *offset_dev = offset;
+}
+
 // ---- q-sample: NCHW fp32 -> NHWC T (Cp) ------------------------------------------------------
 template <typename T>
 __global__ void qsample_kernel(const float* x, const float* noise, const int64_t* ts, const float* sqrtab, const float* sqrtmab,
@@ -261,6 +281,14 @@ extern "C" int dm_randn_slice(float* out, int64_t n, uint64_t seed, uint64_t off
 extern "C" int dm_randn_dev(float* out, int64_t n, uint64_t seed, const uint64_t* offset_dev, dm_stream_t s) {
     DM_CHECK_ARG(out && n > 0 && offset_dev, "dm_randn_dev: bad arguments");
     hipLaunchKernelGGL(randn_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, ST, out, n, seed, (uint64_t)0, offset_dev, (int64_t)0);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+extern "C" int dm_draw_ts_keep(int64_t* ts, float* t_frac, float* keep, int B, int n_T, float keep_prob, uint64_t seed, uint64_t* offset_dev,
+                               dm_stream_t s) {
+    DM_CHECK_ARG(ts && t_frac && keep && offset_dev && B > 0 && n_T > 0 && keep_prob >= 0.f && keep_prob <= 1.f, "dm_draw_ts_keep: bad arguments");
+    hipLaunchKernelGGL(draw_ts_keep_kernel, dim3(1), dim3(256), 0, ST, ts, t_frac, keep, B, n_T, keep_prob, seed, offset_dev);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

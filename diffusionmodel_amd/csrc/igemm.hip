@@ -37,6 +37,7 @@
 // the 8 XCDs, so tile = (bid % 8) * (ntiles / 8) + bid / 8 (bijective form) gives every XCD a contiguous
 // run of tiles — vertically adjacent image rows (shared 3x3 halo) and the n-tiles of one pixel block
 // then meet in the same 4 MiB L2.  Placement only affects speed, never results.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -743,6 +744,223 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
     conv_epilogue<T, 128>(p, acc, smem + half * 4096, tidh, wm4 & 1, wn, fr, fg, mb * 2 + half, mw - (wm4 & 1) * 64, n0);
 }
 
+// =================================================================================================
+// v6: halo-resident kernel for FOUR-tap layers: the 4x4 stride-2 convolution and its input gradient
+// =================================================================================================
+// A 4x4 / stride 2 / pad 1 convolution (new_scripy.py:229, UnetDown.down[4]) re-reads every input pixel for 4 of its 16 taps; on the
+// gather kernel that is 4x the L2->LDS fill of the 3x3 layers per MFMA and the layers ran at 340-490 TFLOP/s.  Split the input into
+// its four pixel-parity sub-images V_g(y, x) = X(2y + py, 2x + px): with (ky - 1) = 2a + py every tap reads ONE sub-image at offset
+// a in {-1, 0, +1} — py = 0: (ky, a) = (1, 0), (3, +1);  py = 1: (0, -1), (2, 0) — so the layer is a sum over (sub-image, 64-channel
+// chunk) of FOUR-tap contributions out of that sub-image's halo, and the halo can stay resident exactly as in the 3x3 kernel (same
+// tile geometry over the OUTPUT image, same LDS image, same fragment addresses).  The sub-images are never materialised: the halo
+// DMA's per-lane pixel offsets simply step by two pixels, the parity is a scalar offset per chunk.  S2 = true is that forward form
+// (weights straight from the [N][16][C] pack).  S2 = false is the input gradient of one output-parity class: a plain 2x2-tap
+// convolution over dy with tap offsets from (ty, tx, oy0, ox0) and a strided output (osy = osx = 2; the epilogue maps it), weights
+// from the per-class transposed pack [c][4][n].
+//   * 4 k-steps per chunk on a 3-stage weight ring: the stage of a step is (4 * chunk + j) % 3, not a compile-time constant as with
+//     9 taps.  It is a scalar: the DMA destination takes it as such, the fragment reads add it to their 8 addresses (8 VALU per
+//     32 MFMAs; three rotating address sets instead cost 16 more VGPRs and pushed the kernel into scratch).
+//   * the tap offset (dy, dx) of a step is a scalar too: a 9-way switch picks the tap body with the offset as an immediate.
+//   * next chunk's halo (<= 54 pieces, 7 per wave) is fetched 3 + 2 + 2 pieces during steps 0..2; waits are compile-time vmcnt.
+template <typename T, int TW, bool S2>
+__global__ __launch_bounds__(512) void conv_tap4_halo_kernel(const ConvP p) {
+    constexpr int TH = TW == 8 ? 8 : 256 / TW, HS = TW == 8 ? 40 : TW + 8, HR = TH + 2, NP = HR * HS / 8;
+    static_assert(NP <= HALO_PIECES, "halo does not fit");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [halo 0][halo 1][w 0][w 1][w 2]
+    char* const sW = smem + 2 * HALO_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm4 = wave & 3, wn = wave >> 2;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nb_n = (p.N + 127) >> 7;
+    const int ntiles = gridDim.x / p.splits;
+    const int split = blockIdx.x / ntiles;
+    const int bid = remap_xcd(blockIdx.x - split * ntiles, ntiles);
+    const int mb = bid / nb_n, nb = bid - mb * nb_n;
+    const int m0 = mb * 256, n0 = nb * 128;
+    const int CK = p.C1;                                   // reduction channels per tap (single source)
+    const int cpg = CK >> 6;                               // 64-channel chunks per sub-image
+    const int nch_total = S2 ? 4 * cpg : cpg;
+    const int c_lo = split * p.kper;
+    const int nchunks = min(nch_total, c_lo + p.kper);
+    const int tiles_img = TW == 8 ? 1 : (p.Hq * TW) >> 8;
+    const int b = TW == 8 ? mb * 4 : mb / tiles_img;
+    const int y0 = TW == 8 ? 0 : (mb - b * tiles_img) * TH;
+
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.N * p.ldw * 2, SRD_FLAGS);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.in1, 0, p.B * p.Hi * p.Wi * CK * 2, SRD_FLAGS);
+
+    const int lrow = lane >> 3;
+    const int slotb = ((lane & 7) ^ lrow) << 4;
+    unsigned hv[7];                                        // halo pieces wave + 8 i: byte offset of the pixel (sub-image 0,0)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int q = min(wave + 8 * i, NP - 1);
+        const int hp = q * 8 + lrow;
+        const int hy = hp / HS, hx = hp - hy * HS;
+        const int img = TW == 8 ? hx / 10 : 0;
+        const int y = y0 + hy - 1, x = TW == 8 ? hx - img * 10 - 1 : hx - 1;        // position in the output-sized (sub-)image
+        const bool ok = (unsigned)y < (unsigned)p.Hq && (unsigned)x < (unsigned)p.Wq && img < 4 && hx < TW + 2 + (TW == 8 ? 30 : 0);
+        const int pix = S2 ? ((b + img) * p.Hi + 2 * y) * p.Wi + 2 * x : ((b + img) * p.Hi + y) * p.Wi + x;
+        hv[i] = ok ? (unsigned)(pix * CK * 2 + slotb) : OOB;
+    }
+    unsigned wv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + (wave * 2 + j) * 8 + lrow;
+        wv[j] = n < p.N ? (unsigned)(n * p.ldw * 2 + slotb) : OOB;
+    }
+    int hoff[3][2][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        int ly, col;
+        if constexpr (TW == 8) {
+            ly = mt * 2 + (fr >> 3);
+            col = wm4 * 10 + (fr & 7);
+        } else {
+            const int g = wm4 * 4 + mt;
+            ly = g / (TW / 16);
+            col = (g - ly * (TW / 16)) * 16 + fr;
+        }
+        const int base = (ly * HS + col) * ROWB;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) hoff[kx][sub][mt] = base + (((sub * 4 + fg) ^ ((col + kx) & 7)) << 4);
+    }
+    int woff[2][4];                                        // weight fragment addresses within stage 0; the stage offset of a step is a scalar
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) woff[sub][nt] = 2 * HALO_BYTES + lds_off(wn * 64 + nt * 16 + fr, sub * 4 + fg);
+
+    // (dy, dx) in {-1, 0, 1}^2 and the weight-row offset of k-step (chunk, j)
+    auto tap_of = [&](int chunk, int j, int& dy, int& dx, int& soff) {
+        if constexpr (S2) {
+            const int g = chunk / cpg, cc = chunk - g * cpg;
+            const int py = g >> 1, px = g & 1;
+            dy = (j >> 1) - py;
+            dx = (j & 1) - px;
+            const int ky = 2 * dy + py + 1, kx = 2 * dx + px + 1;
+            soff = ((ky * 4 + kx) * CK + (cc << 6)) * 2;
+        } else {
+            dy = (j >> 1) * p.ty + p.oy0;
+            dx = (j & 1) * p.tx + p.ox0;
+            soff = (j * CK + (chunk << 6)) * 2;
+        }
+    };
+    auto issue_w = [&](int chunk, int j, int stage) {
+        const bool live = chunk < nchunks;
+        int dy, dx, soff;
+        tap_of(live ? chunk : c_lo, j, dy, dx, soff);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_dst)(sW + stage * WSTAGE + (wave * 2 + k) * 1024), 16, live ? wv[k] : OOB, soff, 0, 0);
+    };
+    auto issue_h = [&](int i, int chunk, int buf) {
+        const bool live = chunk < nchunks;
+        int soff;
+        if constexpr (S2) {
+            const int ch = live ? chunk : c_lo;
+            const int g = ch / cpg, cc = ch - g * cpg;
+            soff = (((g >> 1) * p.Wi + (g & 1)) * CK + (cc << 6)) * 2;
+        } else {
+            soff = (chunk << 6) * 2;
+        }
+        const int q = min(wave + 8 * i, NP - 1);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_dst)(smem + buf * HALO_BYTES + q * 1024), 16, live ? hv[i] : OOB, soff, 0, 0);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int i = 0; i < 7; ++i) issue_h(i, c_lo, 0);
+    issue_w(c_lo, 0, 0);
+    issue_w(c_lo, 1, 1);
+    int hdelta = HALO_BYTES;
+    int s0 = 0;                                            // ring stage of step 0 of the current chunk
+    for (int chunk = c_lo; chunk < nchunks; ++chunk) {
+        const int nbuf = (chunk - c_lo + 1) & 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // everything older than the previous step's group has landed (groups: step 0 = 2 w + 3 h, steps 1, 2 = 2 w + 2 h, step 3 = 2 w)
+            if (j == 0) wait_vmcnt<2>();
+            else if (j == 1) wait_vmcnt<5>();
+            else wait_vmcnt<4>();
+            __builtin_amdgcn_s_barrier();
+            {
+                const int j2 = (j + 2) & 3;
+                int st = s0 + j + 2;
+                st -= st >= 3 ? 3 : 0;
+                st -= st >= 3 ? 3 : 0;
+                issue_w(chunk + (j + 2 >= 4 ? 1 : 0), j2, st);
+            }
+            if (j == 0) { issue_h(0, chunk + 1, nbuf); issue_h(1, chunk + 1, nbuf); issue_h(2, chunk + 1, nbuf); }
+            else if (j == 1) { issue_h(3, chunk + 1, nbuf); issue_h(4, chunk + 1, nbuf); }
+            else if (j == 2) { issue_h(5, chunk + 1, nbuf); issue_h(6, chunk + 1, nbuf); }
+            int dy, dx, soff_unused;
+            tap_of(chunk, j, dy, dx, soff_unused);
+            const int code = (dy + 1) * 3 + (dx + 1);
+            int wst = s0 + j;                                  // ring stage of this step (scalar)
+            wst -= wst >= 3 ? 3 : 0;
+            wst -= wst >= 3 ? 3 : 0;
+            wst *= WSTAGE;
+            auto body = [&](auto KY, auto KX) {
+                constexpr int ky = decltype(KY)::value, kx = decltype(KX)::value;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+                    u32x4 fb[4], fa[4];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) fb[mt] = *(const u32x4*)(smem + hoff[kx][sub][mt] + (ky * HS + kx) * ROWB);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) fa[nt] = *(const u32x4*)(smem + woff[sub][nt] + wst);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) Mma<T>::run(fa[nt], fb[mt], acc[nt][mt]);
+                }
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            switch (code) {
+                case 0: body(I0{}, I0{}); break;
+                case 1: body(I0{}, I1{}); break;
+                case 2: body(I0{}, I2{}); break;
+                case 3: body(I1{}, I0{}); break;
+                case 4: body(I1{}, I1{}); break;
+                case 5: body(I1{}, I2{}); break;
+                case 6: body(I2{}, I0{}); break;
+                case 7: body(I2{}, I1{}); break;
+                default: body(I2{}, I2{}); break;
+            }
+        }
+        // 4 steps = one turn of the 3-stage ring plus one
+        s0 = s0 == 2 ? 0 : s0 + 1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) hoff[kx][sub][mt] += hdelta;
+        hdelta = -hdelta;
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+    const int half = wm4 >> 1;
+    if (p.splits > 1) {
+        store_partial<128>(p, acc, split, ntiles * 2, (mb * 2 + half) * nb_n + nb, (wm4 & 1) + 2 * wn, lane);
+        return;
+    }
+    const int tidh = (((wave & 1) + 2 * wn) << 6) + lane;
+    conv_epilogue<T, 128>(p, acc, smem + half * 4096, tidh, wm4 & 1, wn, fr, fg, mb * 2 + half, m0 + wm4 * 64 - (wm4 & 1) * 64, n0);
+}
+
 int g_last_path = 0;  // kernel family the last dm_conv launch used: 0 = gather (conv_igemm*), 1 = conv3x3_halo_kernel
 
 int g_variant = 5;    // 1 = register staging, 2..4 = LDS-DMA with that many ring stages (2 workgroups/CU at 2),
@@ -825,9 +1043,72 @@ bool halo_eligible(const ConvP& p) {
     return pix * cmax * 2 < (1ll << 31) && (int64_t)p.N * p.ldw * 2 < (1ll << 31);
 }
 
+template <typename T, int TW, bool S2>
+int launch_tap4(const ConvP& p, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_tap4_halo_kernel<T, TW, S2>, hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
+        if (e != hipSuccess) { dm_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", HALO_LDS, hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    const int tiles = (p.M / 256) * cdiv(p.N, 128);
+    ConvP q = p;
+    const int nchunks = (S2 ? 4 : 1) * (p.C1 / 64);
+    if (tiles <= 128 && nchunks >= 4 && dm_g_ws != nullptr) {       // few tiles, deep K: split the chunks over workgroups
+        int splits = 256 / tiles;
+        if (splits > nchunks / 2) splits = nchunks / 2;
+        if (splits >= 2 && (int64_t)splits * tiles * 2 * (128 * 128 * 4) <= dm_g_ws_bytes) {
+            q.kper = cdiv(nchunks, splits);
+            q.splits = cdiv(nchunks, q.kper);
+            q.ws = dm_g_ws;
+        }
+    }
+    hipLaunchKernelGGL((conv_tap4_halo_kernel<T, TW, S2>), dim3((unsigned)(tiles * q.splits)), dim3(512), HALO_LDS, st, q);
+    DM_LAUNCH_CHECK();
+    g_last_path = 2;
+    if (q.splits > 1) {
+        hipLaunchKernelGGL((splitk_epilogue_kernel<T, 128>), dim3((unsigned)(tiles * 2)), dim3(256), 0, st, q);
+        DM_LAUNCH_CHECK();
+    }
+    return DM_OK;
+}
+
+// 0: not eligible; 1: the 4x4 / stride-2 / pad-1 forward form (S2); 2: a 2x2-tap stride-1 gather with offsets in {-1, 0, 1}
+// (the input gradient of one output-parity class of that layer).  Output image rows of 8 (four images per tile), 16, 32 or 64 pixels.
+int g_tap4 = 1;
+int tap4_mode(const ConvP& p) {
+    if (!g_tap4 || p.C2 != 0 || p.C1 % 64 != 0 || p.N < 64 || p.B2 != p.B) return 0;
+    if (p.Wq == 8) { if (p.Hq != 8 || p.B % 4 != 0) return 0; }
+    else if ((p.Wq != 16 && p.Wq != 32 && p.Wq != 64) || (p.Hq * p.Wq) % 256 != 0) return 0;
+    const int64_t in_bytes = (int64_t)p.B * p.Hi * p.Wi * p.C1 * 2;
+    if (in_bytes >= (1ll << 31) || (int64_t)p.N * p.ldw * 2 >= (1ll << 31)) return 0;
+    if (p.T == 16 && p.KW == 4 && p.sy == 2 && p.sx == 2 && p.ty == 1 && p.tx == 1 && p.oy0 == -1 && p.ox0 == -1 && p.Hi == 2 * p.Hq &&
+        p.Wi == 2 * p.Wq && p.Ho == p.Hq && p.Wo == p.Wq && p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0)
+        return 1;
+    if (p.T == 4 && p.KW == 2 && p.sy == 1 && p.sx == 1 && p.Hi == p.Hq && p.Wi == p.Wq && (p.ty == 1 || p.ty == -1) && (p.tx == 1 || p.tx == -1)) {
+        const int dy0 = p.oy0, dy1 = p.ty + p.oy0, dx0 = p.ox0, dx1 = p.tx + p.ox0;
+        if (dy0 < -1 || dy0 > 1 || dy1 < -1 || dy1 > 1 || dx0 < -1 || dx0 > 1 || dx1 < -1 || dx1 > 1) return 0;
+        return 2;
+    }
+    return 0;
+}
+
+template <typename T, bool S2>
+int launch_tap4_tw(const ConvP& p, hipStream_t st) {
+    if (p.Wq == 64) return launch_tap4<T, 64, S2>(p, st);
+    if (p.Wq == 32) return launch_tap4<T, 32, S2>(p, st);
+    if (p.Wq == 16) return launch_tap4<T, 16, S2>(p, st);
+    return launch_tap4<T, 8, S2>(p, st);
+}
+
 template <typename T>
 int launch_conv(const ConvP& p, bool small_offsets, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
+        if (g_variant == 5 && small_offsets) {
+            const int m4 = tap4_mode(p);
+            if (m4 == 1) return launch_tap4_tw<T, true>(p, st);
+            if (m4 == 2) return launch_tap4_tw<T, false>(p, st);
+        }
         if (g_variant == 5 && halo_eligible(p)) {
             const bool flip = p.ty < 0;
             if (p.Wi >= 64) return flip ? launch_halo<T, 64, true>(p, st) : launch_halo<T, 64, false>(p, st);
@@ -876,6 +1157,8 @@ int launch_conv(const ConvP& p, bool small_offsets, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int dm_set_conv_tap4(int on) { g_tap4 = on != 0; return DM_OK; }
 
 extern "C" int dm_set_conv_variant(int variant) {
     DM_CHECK_ARG(variant >= 1 && variant <= 5, "dm_set_conv_variant: 1 (register staging), 2..4 (LDS-DMA ring stages) or 5 (2 + halo-resident 3x3)");

@@ -99,21 +99,30 @@ class DDPM(_HipBlock):
         ops.L.require_device(x)
         dev = x.device
         B = x.shape[0]
-        if ts is None:
-            ts = torch.randint(1, self.n_T + 1, (B,), device=dev)
-        if noise is None:
-            # the stream offset lives on the device (and is advanced there) so that a captured train step draws fresh noise
-            self._rng_calls += 1
+        tfrac = None
+        if ts is None or ctx_mask is None or noise is None:
+            # the stream offset lives on the device and is advanced there, so that a captured train step (hipGraph or launch plan)
+            # draws fresh timesteps, masks and noise on every replay
             if getattr(self, "_rng_dev", None) is None or self._rng_dev.device != dev:
-                self._rng_dev = torch.full((1,), self._rng_calls - 1, dtype=torch.int64, device=dev)
-            self._rng_dev.add_(1)
-            noise = ops.randn(tuple(x.shape), dev, self._seed(), self._rng_dev)
-        if ctx_mask is None:
-            ctx_mask = torch.bernoulli(torch.full((B,), 1.0 - self.drop_prob, device=dev))
+                self._rng_dev = torch.full((1,), self._rng_calls, dtype=torch.int64, device=dev)
+            self._rng_calls += 1
+            ts_d = torch.empty(B, dtype=torch.int64, device=dev)
+            tf_d, keep_d = torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.float32, device=dev)
+            # t ~ U{1..n_T}, keep ~ Bernoulli(1 - drop_prob) (new_scripy.py:405, 413) by the library's Philox; advances the offset by one
+            ops.call("dm_draw_ts_keep", ops.ptr(ts_d), ops.ptr(tf_d), ops.ptr(keep_d), B, int(self.n_T), float(1.0 - self.drop_prob),
+                     self._seed(), ops.ptr(self._rng_dev))
+            if ts is None:
+                ts, tfrac = ts_d, tf_d
+            if ctx_mask is None:
+                ctx_mask = keep_d
+            if noise is None:
+                noise = ops.randn(tuple(x.shape), dev, self._seed(), self._rng_dev)
         ts = ts.to(dev).long()
+        if tfrac is None:
+            tfrac = ts.float() / self.n_T
         net = self.nn_model
         xt = ops.qsample(x.float(), noise, ts, self.sqrtab, self.sqrtmab, net.compute_dtype, _pad8(x.shape[1]))
-        pred = net.decode(net._encode(xt), net.embed(c.to(dev), ts.float() / self.n_T, ctx_mask.to(dev)))
+        pred = net.decode(net._encode(xt), net.embed(c.to(dev), tfrac, ctx_mask.to(dev)))
         return ops.WeightedLoss.apply(pred, noise, attn_mask.to(dev).float().contiguous(), self._loss_constants(dev))
 
     # ------------------------------------------------------------------------------------------

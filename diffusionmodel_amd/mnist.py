@@ -128,21 +128,28 @@ class DDPM(_DDPM):
         ops.L.require_device(x)
         dev = x.device
         B = x.shape[0]
-        if ts is None:
-            ts = torch.randint(1, self.n_T + 1, (B,), device=dev)
-        if noise is None:
-            # the stream offset lives on the device (and is advanced there) so that a captured train step draws fresh noise
-            self._rng_calls += 1
+        tfrac = None
+        if ts is None or context_mask is None or noise is None:
             if getattr(self, "_rng_dev", None) is None or self._rng_dev.device != dev:
-                self._rng_dev = torch.full((1,), self._rng_calls - 1, dtype=torch.int64, device=dev)
-            self._rng_dev.add_(1)
-            noise = ops.randn(tuple(x.shape), dev, self._seed(), self._rng_dev)
-        if context_mask is None:
-            context_mask = torch.bernoulli(torch.full((B,), float(self.drop_prob), device=dev))
+                self._rng_dev = torch.full((1,), self._rng_calls, dtype=torch.int64, device=dev)
+            self._rng_calls += 1
+            ts_d = torch.empty(B, dtype=torch.int64, device=dev)
+            tf_d, drop_d = torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.float32, device=dev)
+            # MNIST_script.py:237, 246: t ~ U{1..n_T}; context_mask ~ Bernoulli(drop_prob) with 1 = drop
+            ops.call("dm_draw_ts_keep", ops.ptr(ts_d), ops.ptr(tf_d), ops.ptr(drop_d), B, int(self.n_T), float(self.drop_prob),
+                     self._seed(), ops.ptr(self._rng_dev))
+            if ts is None:
+                ts, tfrac = ts_d, tf_d
+            if context_mask is None:
+                context_mask = drop_d
+            if noise is None:
+                noise = ops.randn(tuple(x.shape), dev, self._seed(), self._rng_dev)
         ts = ts.to(dev).long()
+        if tfrac is None:
+            tfrac = ts.float() / self.n_T
         net = self.nn_model
         xt = ops.qsample(x.float(), noise, ts, self.sqrtab, self.sqrtmab, net.compute_dtype, _pad8(x.shape[1]))
-        pred = net.decode(net._encode(xt), net.embed(c.to(dev), ts.float() / self.n_T, context_mask.to(dev)))
+        pred = net.decode(net._encode(xt), net.embed(c.to(dev), tfrac, context_mask.to(dev)))
         return ops.WeightedLoss.apply(pred, noise, None, None)
 
     def _eps_cfg(self, x_i, c2, mask2, t2, ctx_embs, dedup):

@@ -23,7 +23,8 @@ from . import _lib as L
 from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, call, dt, ptr
 
 BN_EPS = 1e-5
-BN_SLOTS = 8          # train-mode BatchNorm statistics travel as [BN_SLOTS][C] accumulators folded by the consuming kernel (0: partial rows + finalize launches)
+import os as _os
+BN_SLOTS = int(_os.environ.get("DM_BN_SLOTS", "8"))          # train-mode BatchNorm statistics travel as [BN_SLOTS][C] accumulators folded by the consuming kernel (0: partial rows + finalize launches)
 _EPOCH = [0]          # bumped by the fused optimiser: invalidates packed-weight caches
 _CACHE = {}
 ON_WGRAD = None       # parallel.GradReducer: called with the parameter whose main_grad a weight-gradient launch just completed

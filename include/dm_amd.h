@@ -94,6 +94,8 @@ int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream);
 int dm_set_wgrad_variant(int variant);
 /* 1 when the last dm_conv_wgrad launch used the halo-resident 3x3 kernel, 0 for the per-tap kernels (measurement aid) */
 int dm_last_wgrad_path(void);
+/* 0: keep the 4x4 / stride-2 convolution and its input gradient on the gather kernel (default 1: conv_tap4_halo_kernel) */
+int dm_set_conv_tap4(int on);
 /* Caller-owned device scratch (16-byte aligned) the MFMA kernels may use for split partial sums; it must outlive every
    launch that follows.  One stream at a time: launches that use it are ordered by the stream they are issued on. */
 int dm_set_workspace(void* ws, int64_t bytes);
@@ -240,6 +242,12 @@ int dm_add(const void* a, const void* b, void* y, int dtype, int64_t n, dm_strea
  * DDPM wrapper pieces
  * ---------------------------------------------------------------------------------------------- */
 /* x_t = sqrtab[ts]*x + sqrtmab[ts]*noise, NCHW fp32 in -> NHWC dtype (Cp channels) out (new_scripy.py:408-411) */
+/* The per-sample draws of DDPM.forward (new_scripy.py:405 `_ts = randint(1, n_T+1)`, :413 `bernoulli(1 - drop_prob)`, :415 `_ts / n_T`)
+ * on the device: ts[b] in 1..n_T, t_frac[b] = ts[b] / n_T (fp32), keep[b] in {0, 1} with P(1) = keep_prob — Philox4x32-10 under `seed`
+ * at stream offset *offset_dev + 1, which the launch stores back (the noise drawn next with dm_randn_dev uses the same offset,
+ * a disjoint counter range).  A captured train step therefore draws fresh timesteps / masks on every replay. */
+int dm_draw_ts_keep(int64_t* ts, float* t_frac, float* keep, int B, int n_T, float keep_prob, uint64_t seed, uint64_t* offset_dev,
+                    dm_stream_t s);
 int dm_qsample(const float* x, const float* noise, const int64_t* ts, const float* sqrtab, const float* sqrtmab,
                void* xt, int dtype, int B, int C, int H, int W, int Cp, dm_stream_t s);
 /* weighted MSE + masked L1 (new_scripy.py:417-437); pred/noise NCHW fp32, mask [B][H][W];

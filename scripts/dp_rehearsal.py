@@ -79,4 +79,89 @@ for step in range(3):                                  # step 0 = observation (n
     worst = max(worst, rel)
     assert (early == 0) == (step == 0), early
 assert worst < 1e-5, worst                            # only fp32 atomic ordering of the non-halo weight-gradient kernels differs
+
+# ---- the planned data-parallel step (bench.py's default): the captured step split into segments at the reducer's markers, the
+# all-reduces between them — against the eager data-parallel step from the same state, same draws
+def eager_step():
+    opt.zero_grad()
+    red.begin()
+    loss = ddpm(x, c, am)
+    loss.backward()
+    red.finish()
+    opt.step()
+    return loss
+
+
+def body(st):
+    opt.zero_grad()
+    red.begin(capture=torch.cuda.is_current_stream_capturing())
+    loss = ddpm(st.x, st.c, st.am)
+    loss.backward()
+    red.finish()
+    opt.step()
+    return loss
+
+
+def reset_draws():
+    """Timesteps, keep masks and noise come from the library's Philox stream at a device-resident offset: rewind it in place (the
+    captured step holds a pointer to this very tensor)."""
+    ddpm._rng_calls = 0
+    if getattr(ddpm, "_rng_dev", None) is not None:
+        ddpm._rng_dev.zero_()
+
+
+snap = dict(p=opt.flat_p.clone(), m=opt.exp_avg.clone(), v=opt.exp_avg_sq.clone(), t=opt._step_dev.clone(), step=opt._step,
+            bufs=[b.clone() for b in ddpm.buffers()])
+
+
+def restore():
+    with torch.no_grad():
+        opt.flat_p.copy_(snap["p"]); opt.exp_avg.copy_(snap["m"]); opt.exp_avg_sq.copy_(snap["v"]); opt._step_dev.copy_(snap["t"])
+        for b, s0 in zip(ddpm.buffers(), snap["bufs"]):
+            b.copy_(s0)
+    opt._step = snap["step"]
+    opt.refresh_shadow()
+    from diffusionmodel_amd import ops
+    ops.bump_weight_epoch()
+    ops.refresh_packs()
+
+
+def rank_spread(tag):
+    """max |p_rank - p_rank0| over the flat parameter buffer (0 when the ranks hold identical weights) and the worst parameter."""
+    mine = opt.flat_p.cpu()
+    ref0 = mine.clone()
+    dist.broadcast(ref0, src=0)
+    diff = (mine - ref0).abs()
+    worst = ""
+    if diff.max() > 0:
+        for (pp, off, n), name in zip(opt._slots, names):
+            if diff[off:off + n].max() > 0:
+                worst = f"{name} {diff[off:off + n].max().item():.2e}"
+                break
+    d = torch.tensor([diff.max().item()])
+    dist.all_reduce(d, op=dist.ReduceOp.MAX)
+    print(f"rank {rank} {tag}: max |p - p_rank0| = {d.item():.3e} {worst}")
+    return d.item()
+
+
+reset_draws()
+assert rank_spread("before the optimiser steps") == 0.0
+eager_losses = [float(eager_step()) for _ in range(2)]
+# (gloo reduces device tensors through the host; its two ranks may differ in the last bit of a sum, RCCL's ring does not: allow ulps)
+assert rank_spread("after 2 eager data-parallel steps") <= 1e-6
+p_eager = opt.flat_p.clone()
+restore()
+planned = D.GraphedTrainStep(ddpm, opt, x, c, am, mode="plan", body=body, runner=red.replay)
+restore()                                             # (the constructor restores too; the draws below must start where the eager run started)
+reset_draws()
+plan_losses = [float(planned()) for _ in range(2)]
+torch.cuda.synchronize()
+rel = ((opt.flat_p - p_eager).norm() / (p_eager - snap["p"]).norm().clamp_min(1e-30)).item()
+print(f"rank {rank} planned DP: {planned.plan.n_kernels} kernels in {planned.plan.n_segments} segments (markers {planned.plan.segment_markers}), "
+      f"losses eager {eager_losses} planned {plan_losses}, |p_plan - p_eager| / |update| = {rel:.2e}")
+assert planned.plan.n_segments >= 3 and red.MARK_BACKWARD_DONE in planned.plan.segment_markers
+for a, b in zip(eager_losses, plan_losses):
+    assert abs(a - b) <= 2e-3 * abs(a), (eager_losses, plan_losses)
+assert rel < 0.3, rel                                # Adam turns rounding-level gradient noise into +-lr moves: same band as the single-GPU graph test
+assert rank_spread("after 2 planned data-parallel steps") <= 1e-6, "the ranks' parameters diverged after the planned steps"
 dist.destroy_process_group()

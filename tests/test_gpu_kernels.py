@@ -635,3 +635,47 @@ def test_batched_pack_device_rng_offset_and_paired_reduce():
     call("dm_col_reduce", ptr(p2), 37, 20, ptr(r2), 0)
     call("dm_col_reduce2", ptr(p1), ptr(p2), 37, 20, ptr(o1), ptr(o2))
     assert torch.equal(o1, r1) and torch.equal(o2, r2)
+
+
+TAP4_CASES = [
+    # B, C, Cout, H (= W, input): output rows of H/2 pixels
+    (2, 64, 128, 64),        # rows of 32: four tiles per image, one chunk per parity sub-image
+    (1, 128, 192, 32),       # rows of 16, two chunks per sub-image, ragged N (two n-tiles)
+    (4, 64, 64, 16),         # 8x8 output: four images per tile, N = 64
+    (8, 256, 128, 16),       # 8x8 output, 16 chunks over 2 tiles: the channel chunks are split over workgroups (split-K epilogue)
+    (1, 64, 128, 128),       # rows of 64
+    (2, 128, 136, 64),       # ragged N in the second n-tile
+]
+
+
+@pytest.mark.parametrize("case", TAP4_CASES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv4x4s2_four_tap_halo_kernel_exact_integers(case, dtype):
+    """The 4x4 / stride-2 / pad-1 convolution of UnetDown (new_scripy.py:229) on the four-tap halo kernel (conv_tap4_halo_kernel:
+    forward over the parity sub-images, input gradient one output-parity class per launch with a strided output) — small-integer
+    data, so forward, input gradient and weight gradient must equal F.conv2d bit for bit."""
+    o = ops()
+    from diffusionmodel_amd import _lib
+    lib = _lib.load()
+    B, C, Co, H = case
+    g = torch.Generator().manual_seed(C + Co + H)
+    ri = lambda *s: torch.randint(-1, 2, s, generator=g).float()
+    x, w, b, probe = ri(B, C, H, H), ri(Co, C, 4, 4), ri(Co), ri(B, Co, H // 2, H // 2)
+    w = w * (torch.rand(Co, C, 4, 4, generator=g) < 0.15).float()            # sparse weights keep |y| < 256 (exact in 16 bits)
+    probe = probe * (torch.rand(B, Co, H // 2, H // 2, generator=g) < 0.3).float()
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, stride=2, padding=1)
+    assert yr.abs().max() < 256
+    (yr * probe).sum().backward()
+    assert xr.grad.abs().max() < 256
+    conv = Holder(w, b)
+    xd = nhwc(x, dtype).requires_grad_(True)
+    y = o.conv_bn_act(xd, None, conv, None, o.ConvSpec(4, 4, 2, 1))
+    assert lib.dm_last_conv_path() == 2, "the forward launch did not take the four-tap halo kernel"
+    assert torch.equal(nchw(y), yr.detach())
+    (y.float() * nhwc(probe)).sum().backward()
+    # (the input gradient reduces over Cout: whole 64-channel chunks go to the four-tap kernel, a ragged Cout to the gather kernel)
+    assert lib.dm_last_conv_path() == (2 if Co % 64 == 0 else 0), "unexpected kernel for the input-gradient launches"
+    assert torch.equal(nchw(xd.grad), xr.grad)
+    assert torch.equal(conv.weight.grad.cpu(), wr.grad)
+    assert torch.equal(conv.bias.grad.cpu(), br.grad)

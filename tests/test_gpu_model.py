@@ -461,6 +461,7 @@ def test_overlapped_gradient_reducer_two_ranks_on_one_gpu():
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "step 2" in r.stdout and "4/4" in r.stdout, r.stdout[-1500:]
+    assert "planned DP:" in r.stdout, r.stdout[-1500:]               # the plan-replayed data-parallel step ran and agreed with the eager one
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 0.25)])
