@@ -537,3 +537,41 @@ def test_second_live_optimiser_switches_the_gradient_arena_off():
     del o1, o2, n1, n2
     gc.collect()
     assert first in (True, False)
+
+
+def test_replayed_forward_draws_fresh_timesteps_masks_and_noise():
+    """A captured DDPM.forward replayed as a launch plan (no torch CUDAGraph.replay(), hence no help from torch's graph-safe RNG)
+    must still draw new t / keep mask / noise on every replay: all three come from the library's Philox stream at a device-resident
+    offset that the draw kernel itself advances (dm_draw_ts_keep, dm_randn_dev)."""
+    import diffusionmodel_amd as D
+    from diffusionmodel_amd.graph import LaunchPlan
+    torch.manual_seed(0)
+    ddpm = D.DDPM(D.ContextUnet(3, 32, 4, bottleneck_k=4, dtype=torch.float32), (1e-4, 0.02), 1000, DEV, drop_prob=0.5)
+    ddpm.eval()
+    ddpm.rng_seed = 123
+    x = torch.randn(8, 3, 64, 64, device=DEV).clamp(-1, 1)
+    c = torch.randint(0, 4, (8,), device=DEV)
+    am = torch.ones(8, 64, 64, device=DEV)
+    with torch.no_grad():
+        eager = [ddpm(x, c, am).item() for _ in range(3)]            # offsets 1, 2, 3
+        assert len({round(v, 6) for v in eager}) == 3
+        ddpm._rng_dev.zero_()
+        ddpm._rng_calls = 0
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ddpm(x, c, am)                                           # warm-up (offset 1)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        ddpm._rng_dev.zero_()
+        g = torch.cuda.CUDAGraph(keep_graph=True)
+        with torch.cuda.graph(g):
+            loss = ddpm(x, c, am)
+        plan = LaunchPlan(g)
+        assert not any("random" in nm or "bernoulli" in nm for _, nm in plan.op_names())       # no torch RNG kernels in the step
+        replayed = []
+        for _ in range(3):
+            plan.run()
+            replayed.append(loss.item())
+    assert int(ddpm._rng_dev.item()) == 3
+    assert replayed == pytest.approx(eager, rel=1e-6)                # the same three draws as three eager calls: t, mask and noise all moved
