@@ -164,6 +164,8 @@ template <> __device__ inline void store_vec<f16>(f16* p, const float* f) {
 // caller-owned scratch registered through dm_set_workspace (runtime.hip): split partial sums of the MFMA kernels
 extern float* dm_g_ws;
 extern int64_t dm_g_ws_bytes;
+extern int* dm_g_counters;
+#define DM_WS_COUNTERS 16384
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int grid_for(int64_t work_items, int block, int cap = 256 * 16) {

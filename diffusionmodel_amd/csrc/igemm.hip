@@ -56,6 +56,7 @@ struct ConvP {
     // channel chunks (halo kernel) and leaves its accumulators in ws; splitk_epilogue_kernel adds them up and finishes
     int splits, kper;
     float* ws;
+    int* counters;                               // halo kernels: arrival counter per output tile (the last split to arrive finishes the tile)
     int B2;                                      // batch of the second source (in2 is read at sample b % B2); == B unless broadcast
     int stat_slots;                              // 0: psum / psq are [tiles][N] partial rows; S > 0: [S][N] accumulators, tile mb adds into slot mb % S
     const char* addend;                          // optional tensor of the output's layout / dtype added after the activation (gradient of a forked tensor)
@@ -70,6 +71,39 @@ __device__ __forceinline__ void store_partial(const ConvP& p, const f32x4 (&acc)
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) dst[(nt * 4 + mt) * 64] = acc[nt][mt];
+}
+
+// Split-K without a second launch (halo kernels): every split parks its raw accumulators in ws (store_partial), publishes them
+// (release fence) and counts itself in; the split that arrives LAST (no spinning: whoever it is) adds the others' partials to
+// the accumulators it still holds in registers and runs the ordinary epilogue.  Returns false for the splits that are done.
+__device__ __forceinline__ bool splitk_last_arriver(const ConvP& p, f32x4 (&acc)[4][4], char* smem, int split, int ntiles2, int tile_id,
+                                                    int half_tile, int wave4, int tid, int lane) {
+    store_partial<128>(p, acc, split, ntiles2, half_tile, wave4, lane);
+    __threadfence();                                   // the partials are visible device-wide before the count says so
+    __syncthreads();
+    int* flag = (int*)(smem + 16384);
+    if (tid == 0) {
+        const int old = atomicAdd(p.counters + tile_id, 1);
+        const int last = old == p.splits - 1;
+        if (last) p.counters[tile_id] = 0;             // everyone has arrived: ready for the next launch on this stream
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return false;
+    __threadfence();                                   // acquire: the other splits' partials (written on other XCDs) are read from memory
+    for (int k = 0; k < p.splits; ++k) {
+        if (k == split) continue;
+        const f32x4* src = (const f32x4*)p.ws + ((((size_t)k * ntiles2 + half_tile) * 4 + wave4) * 16) * 64 + lane;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const f32x4 v = __builtin_nontemporal_load(src + (nt * 4 + mt) * 64);
+                acc[nt][mt] += v;
+            }
+    }
+    __syncthreads();                                   // the flag word is LDS the epilogue reuses
+    return true;
 }
 
 __device__ __attribute__((aligned(128))) unsigned int g_zero_page[64];  // source of every padded 16-B vector (v2)
@@ -734,9 +768,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
     wait_vmcnt<0>();                     // the surplus (out-of-range) pieces of the last steps
     __syncthreads();                     // the epilogue reuses the LDS for the statistics fold
     const int half = wm4 >> 1;
-    if (p.splits > 1) {                  // the two 128-row halves are tiles 2 mb, 2 mb + 1 of the 128 x 128 epilogue kernel
-        store_partial<128>(p, acc, split, ntiles * 2, (mb * 2 + half) * nb_n + nb, (wm4 & 1) + 2 * wn, lane);
-        return;
+    if (p.splits > 1) {                  // the two 128-row halves are half-tiles 2 mb, 2 mb + 1 of the partial layout
+        if (p.counters == nullptr) {     // two-launch form: splitk_epilogue_kernel folds the partials
+            store_partial<128>(p, acc, split, ntiles * 2, (mb * 2 + half) * nb_n + nb, (wm4 & 1) + 2 * wn, lane);
+            return;
+        }
+        if (!splitk_last_arriver(p, acc, smem, split, ntiles * 2, bid, (mb * 2 + half) * nb_n + nb, (wm4 & 1) + 2 * wn, tid, lane)) return;
     }
     const int tidh = (((wave & 1) + 2 * wn) << 6) + lane;
     // first output pixel of this wave's 64: linear in the tile for whole-row tiles, its own image row for column tiles
@@ -953,14 +990,23 @@ __global__ __launch_bounds__(512) void conv_tap4_halo_kernel(const ConvP p) {
     wait_vmcnt<0>();
     __syncthreads();
     const int half = wm4 >> 1;
-    if (p.splits > 1) {
-        store_partial<128>(p, acc, split, ntiles * 2, (mb * 2 + half) * nb_n + nb, (wm4 & 1) + 2 * wn, lane);
-        return;
+    if (p.splits > 1) {                  // the two 128-row halves are half-tiles 2 mb, 2 mb + 1 of the partial layout
+        if (p.counters == nullptr) {     // two-launch form: splitk_epilogue_kernel folds the partials
+            store_partial<128>(p, acc, split, ntiles * 2, (mb * 2 + half) * nb_n + nb, (wm4 & 1) + 2 * wn, lane);
+            return;
+        }
+        if (!splitk_last_arriver(p, acc, smem, split, ntiles * 2, bid, (mb * 2 + half) * nb_n + nb, (wm4 & 1) + 2 * wn, tid, lane)) return;
     }
     const int tidh = (((wave & 1) + 2 * wn) << 6) + lane;
     conv_epilogue<T, 128>(p, acc, smem + half * 4096, tidh, wm4 & 1, wn, fr, fg, mb * 2 + half, m0 + wm4 * 64 - (wm4 & 1) * 64, n0);
 }
 
+// halo kernels with split channel chunks: 0 (default) = separate splitk_epilogue_kernel launch, 1 = the last split to arrive finishes the
+// tile in the same launch.  The in-kernel form is bit-exact and 2.0 ms per train step SLOWER (17.6 vs 15.5 ms, same box, r02): the
+// agent-scope release / acquire fences it needs write back and invalidate the XCD's whole L2 (the eight L2s are not coherent with
+// each other), once per workgroup — far more than the 34 epilogue launches of ~13 us it removes.  The same holds for an in-kernel
+// reduction of the weight-gradient splits; cross-workgroup hand-offs stay on kernel boundaries.
+int g_splitk_inkernel = 0;
 int g_last_path = 0;  // kernel family the last dm_conv launch used: 0 = gather (conv_igemm*), 1 = conv3x3_halo_kernel
 
 int g_variant = 5;    // 1 = register staging, 2..4 = LDS-DMA with that many ring stages (2 workgroups/CU at 2),
@@ -1010,12 +1056,13 @@ int launch_halo(const ConvP& p, hipStream_t st) {
             q.kper = cdiv(nchunks, splits);
             q.splits = cdiv(nchunks, q.kper);
             q.ws = dm_g_ws;
+            q.counters = g_splitk_inkernel ? dm_g_counters : nullptr;   // the last split to arrive runs the epilogue in the same launch
         }
     }
     hipLaunchKernelGGL((conv3x3_halo_kernel<T, TW, FLIP>), dim3((unsigned)(tiles * q.splits)), dim3(512), HALO_LDS, st, q);
     DM_LAUNCH_CHECK();
     g_last_path = 1;
-    if (q.splits > 1) {
+    if (q.splits > 1 && q.counters == nullptr) {
         hipLaunchKernelGGL((splitk_epilogue_kernel<T, 128>), dim3((unsigned)(tiles * 2)), dim3(256), 0, st, q);
         DM_LAUNCH_CHECK();
     }
@@ -1061,12 +1108,13 @@ int launch_tap4(const ConvP& p, hipStream_t st) {
             q.kper = cdiv(nchunks, splits);
             q.splits = cdiv(nchunks, q.kper);
             q.ws = dm_g_ws;
+            q.counters = g_splitk_inkernel ? dm_g_counters : nullptr;
         }
     }
     hipLaunchKernelGGL((conv_tap4_halo_kernel<T, TW, S2>), dim3((unsigned)(tiles * q.splits)), dim3(512), HALO_LDS, st, q);
     DM_LAUNCH_CHECK();
     g_last_path = 2;
-    if (q.splits > 1) {
+    if (q.splits > 1 && q.counters == nullptr) {
         hipLaunchKernelGGL((splitk_epilogue_kernel<T, 128>), dim3((unsigned)(tiles * 2)), dim3(256), 0, st, q);
         DM_LAUNCH_CHECK();
     }
@@ -1159,6 +1207,7 @@ int launch_conv(const ConvP& p, bool small_offsets, hipStream_t st) {
 }  // namespace
 
 extern "C" int dm_set_conv_tap4(int on) { g_tap4 = on != 0; return DM_OK; }
+extern "C" int dm_set_splitk_inkernel(int on) { g_splitk_inkernel = on != 0; return DM_OK; }
 
 extern "C" int dm_set_conv_variant(int variant) {
     DM_CHECK_ARG(variant >= 1 && variant <= 5, "dm_set_conv_variant: 1 (register staging), 2..4 (LDS-DMA ring stages) or 5 (2 + halo-resident 3x3)");
@@ -1193,7 +1242,7 @@ extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
     p.T = d->T; p.KW = d->KW; p.ty = d->ty; p.tx = d->tx; p.oy0 = d->oy0; p.ox0 = d->ox0;
     p.Ho = d->Ho; p.Wo = d->Wo; p.osy = d->osy; p.osx = d->osx; p.ooy = d->ooy; p.oox = d->oox;
     p.N = d->N; p.ldw = d->ldw; p.ldc = d->ldc; p.coff = d->coff; p.M = (int)M;
-    p.splits = 1; p.kper = 1 << 24; p.ws = nullptr;
+    p.splits = 1; p.kper = 1 << 24; p.ws = nullptr; p.counters = nullptr;
     p.B2 = d->in2_batch > 0 ? d->in2_batch : d->B;
     p.addend = (const char*)d->addend;
     p.stat_slots = d->stat_slots;

@@ -18,10 +18,17 @@ extern "C" int dm_version(void) { return 100; }
 
 float* dm_g_ws = nullptr;
 int64_t dm_g_ws_bytes = 0;
+int* dm_g_counters = nullptr;        // DM_WS_COUNTERS arrival counters (zero between launches) at the tail of the workspace
 extern "C" int dm_set_workspace(void* ws, int64_t bytes) {
     DM_CHECK_ARG((ws == nullptr) == (bytes == 0) && bytes >= 0 && ((uintptr_t)ws & 15) == 0, "dm_set_workspace: need a 16-byte aligned buffer and its size (or NULL, 0)");
+    DM_CHECK_ARG(ws == nullptr || bytes >= (int64_t)(1 << 20), "dm_set_workspace: the workspace must hold at least 1 MiB");
     dm_g_ws = (float*)ws;
-    dm_g_ws_bytes = bytes;
+    dm_g_ws_bytes = ws ? bytes - DM_WS_COUNTERS * (int64_t)sizeof(int) : 0;
+    dm_g_counters = ws ? (int*)((char*)ws + dm_g_ws_bytes) : nullptr;
+    if (ws) {          // the split-K kernels count arrivals per output tile here; the last arriver resets its counter
+        hipError_t e = hipMemset(dm_g_counters, 0, DM_WS_COUNTERS * sizeof(int));
+        if (e != hipSuccess) { dm_set_error("dm_set_workspace: hipMemset failed: %s", hipGetErrorString(e)); return (int)e; }
+    }
     return DM_OK;
 }
 

@@ -96,6 +96,10 @@ int dm_set_wgrad_variant(int variant);
 int dm_last_wgrad_path(void);
 /* 0: keep the 4x4 / stride-2 convolution and its input gradient on the gather kernel (default 1: conv_tap4_halo_kernel) */
 int dm_set_conv_tap4(int on);
+/* halo kernels with the channel chunks split over workgroups: 0 (default) a separate epilogue launch folds the partials; 1 the last
+   split to arrive folds them and runs the epilogue in the same launch (arrival counters at the tail of the workspace) — measured
+   2 ms per train step slower: its agent-scope fences flush the XCD's L2 once per workgroup */
+int dm_set_splitk_inkernel(int on);
 /* Caller-owned device scratch (16-byte aligned) the MFMA kernels may use for split partial sums; it must outlive every
    launch that follows.  One stream at a time: launches that use it are ordered by the stream they are issued on. */
 int dm_set_workspace(void* ws, int64_t bytes);

@@ -127,6 +127,9 @@ HALO_CASES = [
     (4, 8, 0, 24, 16),       # partial chunk and partial n tile
     (1, 64, 0, 64, 128),     # 128-pixel rows: column tiles of 64, halo columns come from the neighbouring tile
     (2, 64, 64, 136, 128),   # column tiles, concatenated sources, ragged N
+    (4, 256, 0, 128, 8),     # one tile, four chunks: split over two workgroups, the last to arrive folds the partials and finishes
+    (2, 512, 0, 256, 16),    # four tiles x four splits (in-kernel split-K epilogue, two n-tiles)
+    (8, 384, 128, 192, 8),   # split-K with concatenated sources and a ragged second n-tile
 ]
 
 
@@ -679,3 +682,25 @@ def test_conv4x4s2_four_tap_halo_kernel_exact_integers(case, dtype):
     assert torch.equal(nchw(xd.grad), xr.grad)
     assert torch.equal(conv.weight.grad.cpu(), wr.grad)
     assert torch.equal(conv.bias.grad.cpu(), br.grad)
+
+
+def test_splitk_last_arriver_form_is_bit_exact_too():
+    """dm_set_splitk_inkernel(1): the split that arrives last folds the others' partials and runs the epilogue in the same launch
+    (kept as an option; measured slower than the two-launch default because its device-scope fences flush the L2)."""
+    from diffusionmodel_amd import _lib
+    lib = _lib.load()
+    o = ops()
+    assert lib.dm_set_splitk_inkernel(1) == 0
+    try:
+        for (B, C, Co, H) in ((4, 256, 128, 8), (2, 512, 256, 16)):
+            g = torch.Generator().manual_seed(B + C)
+            ri = lambda *s: torch.randint(-1, 2, s, generator=g).float()
+            x, w, b = ri(B, C, H, H), ri(Co, C, 3, 3) * (torch.rand(Co, C, 3, 3, generator=g) < 0.1).float(), ri(Co)
+            yr = F.conv2d(x, w, b, padding=1)
+            assert yr.abs().max() < 256
+            conv = Holder(w, b)
+            for rep in range(3):                                  # the arrival counters must be back at zero after every launch
+                y = o.conv_bn_act(nhwc(x, torch.bfloat16), None, conv, None, o.ConvSpec(3, 3, 1, 1))
+                assert torch.equal(nchw(y), yr)
+    finally:
+        assert lib.dm_set_splitk_inkernel(0) == 0
