@@ -149,3 +149,22 @@ def test_train_on_dataset_directory(tmp_path):
     finally:
         for k, v in saved.items():
             setattr(Cfg, k, v)
+
+
+@pytest.mark.gpu
+def test_mnist_script_train_and_sample_synthetic(tmp_path):
+    """BASELINE configs[0] / SURVEY §2 row 6: `train_mnist` (MNIST_script.py:303-394) restated on synthetic digits — a short run
+    trains (the loss EMA falls), samples at every guidance weight and writes the per-epoch grids."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import MNIST_script as ms
+    imgs, labels = ms.synthetic_digits(96, 10, seed=1)
+    assert imgs.shape == (96, 1, 28, 28) and float(imgs.min()) >= 0 and float(imgs.max()) <= 1
+    ddpm, hist = ms.train_mnist(n_epoch=3, batch_size=32, n_T=6, n_feat=32, lrate=2e-3, save_dir=str(tmp_path) + "/", ws_test=(0.0, 2.0),
+                                data=(imgs, labels), quiet=True, save_model=True)
+    assert len(hist) == 3 and all(h == h for h in hist) and hist[-1] < hist[0]
+    for ep in range(3):
+        for w in (0.0, 2.0):
+            assert os.path.isfile(os.path.join(str(tmp_path), f"image_ep{ep}_w{w}.png"))
+    sd = torch.load(os.path.join(str(tmp_path), "model_2.pth"), map_location="cpu", weights_only=True)
+    assert "nn_model.init_conv.conv1.0.weight" in sd and "sqrtab" in sd
