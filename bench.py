@@ -6,8 +6,11 @@
 Workload (N=1): BASELINE.json configs[1] — new_scripy.py ContextUnet 64x64, n_feat=128, T=1000, bf16,
 batch 64 per GPU; a "step" is one full training step: DDPM.forward (q-sample + denoiser + weighted loss)
 + backward + clip_grad_norm_(1.0) + AdamW, on synthetic inputs already resident in HBM.
-N>1: one process per GPU (torchrun), batch 64 per rank (weak scaling), RCCL all-reduce of the flat
-gradient; `value` is the whole-job rate N*K/T.  Rank 0 prints ONE JSON line.
+N>1: one process per GPU — under torchrun, or started by this script itself when WORLD_SIZE is not set (`python bench.py
+--gpus N`: the parent makes no GPU call, starts N ranks and relays rank 0's line) — batch 64 per rank (weak scaling), RCCL
+all-reduce of the flat gradient in buckets between the segments of the replayed step; `value` is the whole-job rate N*K/T.
+Rank 0 prints ONE JSON line (`ranks` = the world size RCCL saw, `devices` = every rank's device).  The step runs as a launch
+plan by default (`--exec plan|graph|eager`).
 
 Extra objects in the line: `roofline` for the dominant kernel (the bf16 implicit-GEMM convolution:
 algorithmic FLOPs of every launch inside the timed region / HIP-event time of those launches, against the
@@ -446,10 +449,10 @@ def main():
     # command (they cannot be collected from inside the process); the committed summary is quoted when present
     traffic, traffic_src = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")) as f:
             pmc = json.load(f)["kernels"].get("conv3x3_halo<bf16>" if dtype == torch.bfloat16 else "", None)
         if pmc and args.n_feat == 128 and args.size == 64 and args.batch == 64:
-            traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)"
+            traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r02_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this command, scripts/pmc_collect.sh)"
     except (OSError, KeyError, ValueError):
         pass
     roofline = {"bound": "mfma", "kernel": ("conv3x3_halo_kernel<%s> (dm_conv forward + input-gradient launches of the 3x3 layers)" if dom == "conv_halo"
