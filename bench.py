@@ -276,6 +276,10 @@ def main():
     ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=8)
     ap.add_argument("--cpu-iters", dest="cpu_iters", type=int, default=3)
     ap.add_argument("--launch-selftest", dest="launch_selftest", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, one rank per GPU).  gloo is a REHEARSAL mode: the ranks may share devices (rank r uses device "
+                         "r %% device_count; the library then selects its <= 64-KiB-LDS kernels), collectives go through the host — it "
+                         "exercises the whole N-rank path of this script on a box with fewer GPUs, its numbers mean nothing")
     ap.add_argument("--buckets", type=int, default=6)
     ap.add_argument("--exec", dest="exec_mode", default="plan", choices=["plan", "graph", "eager"],
                     help="plan (default): the step is captured once and re-issued from C as plain launches (dm_plan_run; data parallel: "
@@ -291,7 +295,7 @@ def main():
         # not under torchrun: be the launcher (no GPU call has been made in this process)
         if not args.launch_selftest:
             have = torch.cuda.device_count()
-            if have < args.gpus:
+            if have < args.gpus and not (args.backend == "gloo" and have >= 1):
                 raise SystemExit(f"--gpus {args.gpus} but only {have} HIP device(s) are visible")
         os.dup2(json_out.fileno(), 1)
         return self_launch(sys.argv[1:], args.gpus)
@@ -301,7 +305,10 @@ def main():
 
     import diffusionmodel_amd as D
     from diffusionmodel_amd import ops, parallel
-    rank, world, local = parallel.init_from_env("nccl", force=args.force_dp)
+    if args.backend == "gloo":                 # rehearsal: ranks may share a device
+        os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+    rank, world, local = parallel.init_from_env(args.backend, force=args.force_dp)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
                          "(or run `python bench.py --gpus N` without WORLD_SIZE set: it starts its own ranks)")
@@ -516,7 +523,7 @@ def main():
                "config": {"workload": "new_scripy.py ContextUnet %dx%d n_feat=%d T=1000 %s, train step batch=%d per GPU (BASELINE configs[%d])"
                                       % (args.size, args.size, args.n_feat, args.dtype, args.batch, 1 if world == 1 else 2),
                           "global_batch": args.batch * world, "bottleneck_k": args.bottleneck_k, "n_classes": 4,
-                          "parallelism": "dp%d" % world, "exec": mode, "host_ms_one_step_idle_queue": round(t_host_one * 1e3, 3), "samples_per_s": round(value * args.batch, 2)},
+                          "parallelism": "dp%d" % world, "backend": args.backend if use_dp else None, "exec": mode, "host_ms_one_step_idle_queue": round(t_host_one * 1e3, 3), "samples_per_s": round(value * args.batch, 2)},
                "loss": final_loss, "roofline": roofline, "cpu_baseline": cpu, "sample": sample}
         print(json.dumps(out), file=json_out, flush=True)
     if use_dp:

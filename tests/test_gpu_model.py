@@ -619,3 +619,25 @@ def test_full_length_trajectory_against_the_oracle():
     print(f"1000-step trajectory w={w}: max|x - oracle| = {err:.2e}, pixel std {ref.std().item():.2f}, max |x| {ref.abs().max().item():.1f}")
     assert torch.isfinite(xs).all()
     assert err < 1e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2 --backend gloo` on a one-GPU box: the self-launcher starts two ranks that share cuda:0 (the library's
+    shared-device guard selects the <= 64-KiB-LDS kernels), the train step runs as a launch plan with the bucketed all-reduce
+    between its segments, sampling is sharded over the ranks, rank 0 prints ONE JSON line with ranks = 2.  The N-rank code path of
+    the driver's scaling run, end to end (its numbers mean nothing here)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--sample-steps", "2", "--no-cpu-baseline", "--batch", "16"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and len(out["devices"]) == 2 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 32 and out["config"]["exec"] == "plan" and out["config"]["backend"] == "gloo"
+    assert out["value"] > 0 and out["loss"] == out["loss"] and out["sample"]["n"] == 32 and "error" not in out["sample"]
+    assert "ranks share 1 device" in r.stderr
