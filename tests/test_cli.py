@@ -146,6 +146,14 @@ def test_train_on_dataset_directory(tmp_path):
         ddpm, hist = ns.train_model(max_epochs=1, quiet=True, data_root=root)
         assert ddpm.n_classes == 2 and len(hist) == 1
         assert torch.isfinite(torch.tensor(hist[0]["train_loss"])) and torch.isfinite(torch.tensor(hist[0]["val_loss"]))
+        # --mode generate with the dataset at hand: class names and the real images of the quality pass come from it (new_scripy.py:960-961, 1001-1029)
+        out = ns.gen_samples(os.path.join(Cfg.SAVE_DIR, "ckpt_ep0.pt"), n_samples_per_class=2, guide_scales=[2.0], data_root=root)
+        d = os.path.dirname(out[2.0]["grid_path"])
+        assert out[2.0]["samples"].shape == (4, 3, 64, 64)
+        assert all(os.path.isfile(os.path.join(d, f"{cls}_s{k}_g2.0.png")) for cls in ("crack_a", "crack_b") for k in (0, 1))
+        import json
+        q = json.load(open(os.path.join(d, "quality_metrics.json")))
+        assert set(q["2.0"]) >= {"ssim", "psnr"}
     finally:
         for k, v in saved.items():
             setattr(Cfg, k, v)
