@@ -65,10 +65,11 @@ class LaunchPlan:
         return out
 
     def foreign_kernels(self):
-        """Kernel names in the plan that are not libdm_amd's (torch-issued elementwise / fill / copy kernels): {name: count}."""
+        """Kernels in the plan that are not libdm_amd's — torch-issued elementwise / fill / copy / RNG kernels (mangled `at::…` names)
+        or runtime copy kernels: {name: count}.  A planned train step holds a handful (fills of the gradient buffers, the step count)."""
         tally = {}
         for kind, nm in self.op_names():
-            if kind == 0 and "at::native" in nm or kind == 0 and "rocclr" in nm or kind == 0 and "at::cuda" in nm:
+            if kind == 0 and ("_ZN2at" in nm or "at::" in nm or "rocclr" in nm):
                 tally[nm] = tally.get(nm, 0) + 1
         return tally
 
