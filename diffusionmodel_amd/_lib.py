@@ -35,6 +35,7 @@ class DmWgrad(C.Structure):
 # name -> argument ctypes (the trailing dm_stream_t is appended automatically unless noted)
 _PROTOS = {
     "dm_conv": [C.POINTER(DmConv)],
+    "dm_conv_parity4": [C.POINTER(DmConv)],
     "dm_conv_wgrad": [C.POINTER(DmWgrad)],
     "dm_pack_w": [vp, vp, i32, i32, i32, i32, i32],
     "dm_pack_wT": [vp, vp, i32, i32, i32, i32, i32, C.POINTER(i32), i32],

@@ -57,6 +57,11 @@ struct ConvP {
     int splits, kper;
     float* ws;
     int* counters;                               // halo kernels: arrival counter per output tile (the last split to arrive finishes the tile)
+    // four-tap kernel, S2 = false: `npar` (1 or 4) output-parity classes in ONE launch — class q takes workgroups [q, q + 1) * grid / npar,
+    // its own transposed weight pack, tap offsets and output offsets (the four input-gradient launches of a 4x4 / stride-2 layer)
+    int npar;
+    const char* w4[4];
+    int oy4[4], ox4[4], ooy4[4], oox4[4];
     int B2;                                      // batch of the second source (in2 is read at sample b % B2); == B unless broadcast
     int stat_slots;                              // 0: psum / psq are [tiles][N] partial rows; S > 0: [S][N] accumulators, tile mb adds into slot mb % S
     const char* addend;                          // optional tensor of the output's layout / dtype added after the activation (gradient of a forked tensor)
@@ -800,20 +805,31 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
 //   * the tap offset (dy, dx) of a step is a scalar too: a 9-way switch picks the tap body with the offset as an immediate.
 //   * next chunk's halo (<= 54 pieces, 7 per wave) is fetched 3 + 2 + 2 pieces during steps 0..2; waits are compile-time vmcnt.
 template <typename T, int TW, bool S2>
-__global__ __launch_bounds__(512) void conv_tap4_halo_kernel(const ConvP p) {
+__global__ __launch_bounds__(512) void conv_tap4_halo_kernel(const ConvP pp) {
     constexpr int TH = TW == 8 ? 8 : 256 / TW, HS = TW == 8 ? 40 : TW + 8, HR = TH + 2, NP = HR * HS / 8;
     static_assert(NP <= HALO_PIECES, "halo does not fit");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [halo 0][halo 1][w 0][w 1][w 2]
     char* const sW = smem + 2 * HALO_BYTES;
+
+    // parity class of this workgroup (S2 = false with npar = 4): its weight pack, tap offsets and output offsets replace the descriptor's
+    ConvP p = pp;
+    const int gpar = (int)gridDim.x / pp.npar;             // workgroups per parity class
+    const int par = (int)blockIdx.x / gpar;
+    const int blk = (int)blockIdx.x - par * gpar;
+    if (!S2 && pp.npar > 1) {
+        p.w = pp.w4[par];
+        p.oy0 = pp.oy4[par]; p.ox0 = pp.ox4[par];
+        p.ooy = pp.ooy4[par]; p.oox = pp.oox4[par];
+    }
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm4 = wave & 3, wn = wave >> 2;
     const int fr = lane & 15, fg = lane >> 4;
     const int nb_n = (p.N + 127) >> 7;
-    const int ntiles = gridDim.x / p.splits;
-    const int split = blockIdx.x / ntiles;
-    const int bid = remap_xcd(blockIdx.x - split * ntiles, ntiles);
+    const int ntiles = gpar / p.splits;
+    const int split = blk / ntiles;
+    const int bid = remap_xcd(blk - split * ntiles, ntiles);
     const int mb = bid / nb_n, nb = bid - mb * nb_n;
     const int m0 = mb * 256, n0 = nb * 128;
     const int CK = p.C1;                                   // reduction channels per tap (single source)
@@ -991,6 +1007,7 @@ __global__ __launch_bounds__(512) void conv_tap4_halo_kernel(const ConvP p) {
     __syncthreads();
     const int half = wm4 >> 1;
     if (p.splits > 1) {                  // the two 128-row halves are half-tiles 2 mb, 2 mb + 1 of the partial layout
+        // (never with npar > 1: the launcher takes all four classes in one launch only when that fills the chip without a split)
         if (p.counters == nullptr) {     // two-launch form: splitk_epilogue_kernel folds the partials
             store_partial<128>(p, acc, split, ntiles * 2, (mb * 2 + half) * nb_n + nb, (wm4 & 1) + 2 * wn, lane);
             return;
@@ -1098,10 +1115,10 @@ int launch_tap4(const ConvP& p, hipStream_t st) {
         if (e != hipSuccess) { dm_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", HALO_LDS, hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
-    const int tiles = (p.M / 256) * cdiv(p.N, 128);
+    const int tiles = (p.M / 256) * cdiv(p.N, 128) * p.npar;
     ConvP q = p;
     const int nchunks = (S2 ? 4 : 1) * (p.C1 / 64);
-    if (tiles <= 128 && nchunks >= 4 && dm_g_ws != nullptr) {       // few tiles, deep K: split the chunks over workgroups
+    if (p.npar == 1 && tiles <= 128 && nchunks >= 4 && dm_g_ws != nullptr) {       // few tiles, deep K: split the chunks over workgroups
         int splits = 256 / tiles;
         if (splits > nchunks / 2) splits = nchunks / 2;
         if (splits >= 2 && (int64_t)splits * tiles * 2 * (128 * 128 * 4) <= dm_g_ws_bytes) {
@@ -1218,9 +1235,49 @@ extern "C" int dm_set_conv_variant(int variant) {
 extern "C" int dm_last_conv_path(void) { return g_last_path; }
 extern "C" int dm_get_conv_variant(void) { return g_variant; }
 
-extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
+static int conv_fill(const DmConv* d, ConvP& p, bool& small);
+
+// Four descriptors that differ only in w, oy0, ox0, ooy, oox — the input-gradient launches of the four output-parity classes of a
+// stride-2 layer: ONE launch of the four-tap halo kernel when that is eligible and fills the chip without a K split, otherwise four
+// dm_conv calls.
+extern "C" int dm_conv_parity4(const DmConv* d4, dm_stream_t stream) {
+    DM_CHECK_ARG(d4 != nullptr, "dm_conv_parity4: null descriptors");
+    ConvP p[4];
+    bool small[4];
+    for (int i = 0; i < 4; ++i) {
+        const int rc = conv_fill(d4 + i, p[i], small[i]);
+        if (rc != DM_OK) return rc;
+    }
+    bool same = d4[0].dtype != DM_F32 && g_variant == 5 && small[0];
+    for (int i = 1; i < 4 && same; ++i) {
+        const DmConv &a = d4[0], &b = d4[i];
+        same = a.in1 == b.in1 && a.in2 == b.in2 && a.out == b.out && a.addend == b.addend && a.scale == b.scale && a.shift == b.shift &&
+               a.psum == nullptr && b.psum == nullptr && a.dtype == b.dtype && a.act == b.act && a.out_nchw_f32 == 0 && b.out_nchw_f32 == 0 &&
+               a.B == b.B && a.Hi == b.Hi && a.Wi == b.Wi && a.C1 == b.C1 && a.C2 == b.C2 && a.Hq == b.Hq && a.Wq == b.Wq && a.sy == b.sy &&
+               a.sx == b.sx && a.T == b.T && a.KW == b.KW && a.ty == b.ty && a.tx == b.tx && a.Ho == b.Ho && a.Wo == b.Wo && a.osy == b.osy &&
+               a.osx == b.osx && a.N == b.N && a.ldw == b.ldw && a.ldc == b.ldc && a.coff == b.coff && a.in2_batch == b.in2_batch;
+    }
+    if (same) for (int i = 0; i < 4 && same; ++i) same = tap4_mode(p[i]) == 2;
+    const int tiles1 = (int)((p[0].M / 256) * cdiv(p[0].N, 128));
+    if (same && 4 * tiles1 >= 192) {               // the four classes together fill the chip: no K split, one launch
+        ConvP q = p[0];
+        q.npar = 4;
+        for (int i = 0; i < 4; ++i) {
+            q.w4[i] = p[i].w; q.oy4[i] = p[i].oy0; q.ox4[i] = p[i].ox0; q.ooy4[i] = p[i].ooy; q.oox4[i] = p[i].oox;
+        }
+        hipStream_t st = (hipStream_t)stream;
+        if (d4[0].dtype == DM_BF16) return launch_tap4_tw<bf16, false>(q, st);
+        return launch_tap4_tw<f16, false>(q, st);
+    }
+    for (int i = 0; i < 4; ++i) {
+        const int rc = dm_conv(d4 + i, stream);
+        if (rc != DM_OK) return rc;
+    }
+    return DM_OK;
+}
+
+static int conv_fill(const DmConv* d, ConvP& p_out, bool& small_out) {
     DM_CHECK_ARG(d != nullptr, "dm_conv: null descriptor");
-    g_last_path = 0;
     const int ve = d->dtype == DM_F32 ? 4 : 8;
     DM_CHECK_ARG(d->dtype == DM_F32 || d->dtype == DM_BF16 || d->dtype == DM_F16, "dm_conv: bad dtype %d", d->dtype);
     DM_CHECK_ARG(d->in1 && d->w && d->out, "dm_conv: null tensor pointer");
@@ -1234,7 +1291,7 @@ extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
     DM_CHECK_ARG(((uintptr_t)d->in1 & 15) == 0 && ((uintptr_t)d->in2 & 15) == 0 && ((uintptr_t)d->w & 15) == 0, "dm_conv: tensors must be 16-byte aligned");
     const int64_t M = (int64_t)d->B * d->Hq * d->Wq;
     DM_CHECK_ARG(M < (1ll << 31), "dm_conv: M too large");
-    ConvP p;
+    ConvP& p = p_out;
     p.in1 = (const char*)d->in1; p.in2 = (const char*)d->in2; p.w = (const char*)d->w;
     p.scale = d->scale; p.shift = d->shift; p.out = (char*)d->out; p.psum = d->psum; p.psq = d->psq;
     p.act = d->act; p.out_nchw = d->out_nchw_f32;
@@ -1242,7 +1299,7 @@ extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
     p.T = d->T; p.KW = d->KW; p.ty = d->ty; p.tx = d->tx; p.oy0 = d->oy0; p.ox0 = d->ox0;
     p.Ho = d->Ho; p.Wo = d->Wo; p.osy = d->osy; p.osx = d->osx; p.ooy = d->ooy; p.oox = d->oox;
     p.N = d->N; p.ldw = d->ldw; p.ldc = d->ldc; p.coff = d->coff; p.M = (int)M;
-    p.splits = 1; p.kper = 1 << 24; p.ws = nullptr; p.counters = nullptr;
+    p.splits = 1; p.kper = 1 << 24; p.ws = nullptr; p.counters = nullptr; p.npar = 1;
     p.B2 = d->in2_batch > 0 ? d->in2_batch : d->B;
     p.addend = (const char*)d->addend;
     p.stat_slots = d->stat_slots;
@@ -1258,6 +1315,16 @@ extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
     const int64_t in_elems = (int64_t)d->B * d->Hi * d->Wi * (d->C1 > d->C2 ? d->C1 : d->C2);
     const int64_t w_elems = (int64_t)d->N * d->ldw;
     const bool small = in_elems < (1ll << 31) - (1ll << 24) && w_elems < (1ll << 31);
+    small_out = small;
+    return DM_OK;
+}
+
+extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
+    g_last_path = 0;
+    ConvP p;
+    bool small;
+    const int rc = conv_fill(d, p, small);
+    if (rc != DM_OK) return rc;
     if (d->dtype == DM_BF16) return launch_conv<bf16>(p, small, (hipStream_t)stream);
     if (d->dtype == DM_F16) return launch_conv<f16>(p, small, (hipStream_t)stream);
     return launch_conv<float>(p, small, (hipStream_t)stream);

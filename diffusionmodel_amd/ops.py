@@ -266,12 +266,12 @@ def _desc_cache():
     return c
 
 
-def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0,
+def _conv_desc(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0,
                Ho, Wo, N, osy=1, osx=1, ooy=0, oox=0, ldc=None, coff=0, scale=None, shift=None, act=ACT_NONE,
                psum=None, psq=None, out_nchw=False, in2_batch=0, addend=None, stat_slots=0):
-    L.ensure_workspace()          # split-K partial tiles of small, deep problems
-    # the geometry half of the descriptor is the same every step: one ctypes struct per distinct call, only the eight pointers
-    # change (filling 37 fields costs ~6 us of Python per launch; the backward pass runs on autograd's thread, hence per thread)
+    """The filled DmConv descriptor of one launch.  The geometry half is the same every step: one ctypes struct per distinct call,
+    only the pointers change (filling 37 fields costs ~6 us of Python per launch; the backward pass runs on autograd's thread, hence
+    a cache per thread)."""
     key = (dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0, Ho, Wo, N, osy, osx, ooy, oox, ldc, coff, act,
            out_nchw, in2_batch, ldw, stat_slots)
     cache = _desc_cache()
@@ -290,6 +290,13 @@ def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, s
     d.in1, d.in2, d.w = ptr(in1), ptr(in2), w_ptr
     d.scale, d.shift, d.out, d.psum, d.psq = ptr(scale), ptr(shift), ptr(out), ptr(psum), ptr(psq)
     d.addend = ptr(addend)
+    return d
+
+
+def _conv_call(in1, in2, w_ptr, ldw, out, **kw):
+    L.ensure_workspace()          # split-K partial tiles of small, deep problems
+    d = _conv_desc(in1, in2, w_ptr, ldw, out, **kw)
+    dtype, B, Hi, Wi, C1, C2, Hq, Wq, N, T, sy, ty = (kw[k] for k in ("dtype", "B", "Hi", "Wi", "C1", "C2", "Hq", "Wq", "N", "T", "sy", "ty"))
     kind = "conv_igemm" if dtype != torch.float32 else "igemm_f32"
     if PROFILE_META is not None:
         call("dm_conv", C.byref(d))
@@ -305,7 +312,32 @@ def _conv_call(in1, in2, w_ptr, ldw, out, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, s
         if kind == "conv_igemm" and L.load().dm_last_conv_path() == 1:
             kind = "conv_halo"                # the launch went to conv3x3_halo_kernel
         PROFILE.append((kind, 2.0 * B * Hq * Wq * N * T * (C1 + C2), e0, e1,
-                        f"B{B} {Hi}x{Wi} C{C1}+{C2} N{N} T{T} s{sy} t{ty} o{oy0} out{Ho}x{Wo}/{osy}"))
+                        f"B{B} {Hi}x{Wi} C{C1}+{C2} N{N} T{T} s{sy} t{ty} o{kw['oy0']} out{kw['Ho']}x{kw['Wo']}/{kw.get('osy', 1)}"))
+
+
+def _conv_parity4_call(calls):
+    """Four (in1, in2, w_ptr, ldw, out, kwargs) launches that differ only in weights / tap offsets / output offsets — the four
+    output-parity classes of a stride-2 layer's input gradient: one dm_conv_parity4 call (one launch where the four-tap halo kernel
+    takes it, four otherwise)."""
+    L.ensure_workspace()
+    arr = (L.DmConv * 4)()
+    flops = 0.0
+    for i, (in1, in2, w_ptr, ldw, out, kw) in enumerate(calls):
+        d = _conv_desc(in1, in2, w_ptr, ldw, out, **kw)
+        C.memmove(C.byref(arr, i * C.sizeof(L.DmConv)), C.byref(d), C.sizeof(L.DmConv))
+        flops += 2.0 * kw["B"] * kw["Hq"] * kw["Wq"] * kw["N"] * kw["T"] * (kw["C1"] + kw["C2"])
+    kw = calls[0][5]
+    kind = "conv_igemm" if kw["dtype"] != torch.float32 else "igemm_f32"
+    if PROFILE is not None and kind in PROFILE_KINDS:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call("dm_conv_parity4", arr)
+        e1.record()
+        PROFILE.append((kind, flops, e0, e1, f"B{kw['B']} {kw['Hi']}x{kw['Wi']} C{kw['C1']} N{kw['N']} T4 x4 parity classes"))
+    else:
+        call("dm_conv_parity4", arr)
+        if PROFILE_META is not None:
+            PROFILE_META.append((kind, flops, f"B{kw['B']} {kw['Hi']}x{kw['Wi']} C{kw['C1']} N{kw['N']} T4 x4 parity classes"))
 
 
 def _wgrad_call(dy, in1, in2, dw, dbias, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0, Ho, Wo, N, ldy,
@@ -552,6 +584,7 @@ class ConvBnAct(torch.autograd.Function):
                     raise L.DmError("conv backward: gradient w.r.t. a channel-padded input is not supported")
                 if Hi % s or Wi % s:
                     raise L.DmError("conv backward: strided conv needs input size divisible by the stride")
+                launches = []
                 for py in range(s):
                     for px in range(s):
                         ky0, kx0 = (py + p) % s, (px + p) % s
@@ -559,10 +592,14 @@ class ConvBnAct(torch.autograd.Function):
                         wt = packed_T(w, dtype, taps, ldy)
                         # rows c_lo .. c_lo+c_n of the [C][Tt][ldy] pack
                         row_bytes = len(taps) * ldy * wt.element_size()
-                        _conv_call(dz, None, wt.data_ptr() + c_lo * row_bytes, len(taps) * ldy, dxi, dtype=dtype, B=B, Hi=Ho, Wi=Wo,
-                                   C1=ldy, C2=0, Hq=Hi // s, Wq=Wi // s, sy=1, sx=1, T=len(taps), KW=kw // s, ty=-1, tx=-1,
-                                   oy0=(py + p - ky0) // s, ox0=(px + p - kx0) // s, Ho=Hi, Wo=Wi, osy=s, osx=s, ooy=py, oox=px,
-                                   N=c_n, addend=add_i)
+                        launches.append((dz, None, wt.data_ptr() + c_lo * row_bytes, len(taps) * ldy, dxi, dict(
+                            dtype=dtype, B=B, Hi=Ho, Wi=Wo, C1=ldy, C2=0, Hq=Hi // s, Wq=Wi // s, sy=1, sx=1, T=len(taps), KW=kw // s, ty=-1, tx=-1,
+                            oy0=(py + p - ky0) // s, ox0=(px + p - kx0) // s, Ho=Hi, Wo=Wi, osy=s, osx=s, ooy=py, oox=px, N=c_n, addend=add_i)))
+                if len(launches) == 4:          # stride 2: the four output-parity classes in one call (one launch on the four-tap halo kernel)
+                    _conv_parity4_call(launches)
+                else:
+                    for (a1, a2, wp_, ldw_, o_, kw_) in launches:
+                        _conv_call(a1, a2, wp_, ldw_, o_, **kw_)
                 outs.append(dxi)
             dx = outs[0]
             dx2 = outs[1] if x2 is not None else None

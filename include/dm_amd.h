@@ -67,6 +67,10 @@ typedef struct DmConv {
                                                      accumulation of new_scripy.py's skip / residual tensors) */
 } DmConv;
 int dm_conv(const DmConv* d, dm_stream_t stream);
+/* d4[0..3]: four descriptors that differ only in w, oy0, ox0, ooy, oox — the input-gradient launches of the four output-parity classes
+ * of a stride-2 layer (new_scripy.py:229).  One launch of the four-tap halo kernel when it is eligible and the four classes together
+ * fill the chip; otherwise equivalent to four dm_conv calls. */
+int dm_conv_parity4(const DmConv* d4, dm_stream_t stream);
 /* tuning knob: staging pipeline of dm_conv — 1 = register staging, 2..4 = LDS-DMA gather ring with that many stages,
    5 (default) = halo-resident kernel for 3x3 stride-1 layers on 16/32/64-pixel rows with 64-channel multiples, gather ring otherwise */
 int dm_set_conv_variant(int variant);

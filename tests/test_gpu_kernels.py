@@ -648,6 +648,8 @@ TAP4_CASES = [
     (8, 256, 128, 16),       # 8x8 output, 16 chunks over 2 tiles: the channel chunks are split over workgroups (split-K epilogue)
     (1, 64, 128, 128),       # rows of 64
     (2, 128, 136, 64),       # ragged N in the second n-tile
+    (16, 64, 128, 64),       # enough tiles that the four parity classes of the input gradient go out as ONE launch (dm_conv_parity4)
+    (256, 64, 64, 16),       # the same with 8x8 outputs (four images per tile)
 ]
 
 
