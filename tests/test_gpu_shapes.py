@@ -85,3 +85,31 @@ def test_cfg5_train_steps_and_sampling(dtype):
     ddpm.eval()
     xs = ddpm.sample(4, (3, 128, 128), DEV, guide_w=2.0, steps=2, seed=3)
     assert torch.isfinite(xs).all().item()
+
+
+@pytest.mark.parametrize("dtype,bar", [(torch.float32, 1e-9), (torch.float16, 2.5e-6), (torch.bfloat16, 2e-4)], ids=["fp32", "fp16", "bf16"])
+def test_cfg5_forward_against_the_oracle(dtype, bar):
+    """BASELINE configs[4] at its stated size — 128x128, n_feat = 256 (627 M parameters), k = 8, CoordAttn on — eval-mode eps of ONE
+    sample against the fp32 CPU oracle on the same seeded weights: relative MSE (eps error power / eps power).  fp32 sits at rounding
+    level (1.4e-12); the 16-bit bars are about 5x the measured values (fp16 4.9e-7, bf16 3.5e-5)."""
+    import diffusionmodel_amd as D
+    torch.manual_seed(11)
+    net = D.ContextUnet(3, 256, 4, bottleneck_k=8, dtype=dtype)
+    with torch.no_grad():
+        for n_, b in net.named_buffers():
+            if n_.endswith("running_mean"):
+                b.normal_(0, 0.1)
+            elif n_.endswith("running_var"):
+                b.uniform_(0.6, 1.4)
+    sd = {k: v.detach().clone().cpu() for k, v in net.state_dict().items()}
+    net = net.to(DEV).eval()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 3, 128, 128, generator=g).clamp_(-1, 1)
+    c, t, mk = torch.tensor([2]), torch.tensor([0.37]), torch.tensor([1.0])
+    with torch.no_grad():
+        eps = net(x.to(DEV), c.to(DEV), t.to(DEV), mk.to(DEV)).cpu().double()
+        torch.set_num_threads(16)
+        ref = O.context_unet(sd, x, c, t, mk, False).double()
+    rel = float(((eps - ref) ** 2).mean() / (ref ** 2).mean())
+    print(f"cfg-5 eval eps, {dtype}: relative MSE {rel:.3e}, max abs {float((eps - ref).abs().max()):.3e}, eps power {float((ref ** 2).mean()):.3e}")
+    assert torch.isfinite(eps).all() and rel < bar
