@@ -226,7 +226,54 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 
 
     const bool vec_ok = ((p.ldc | p.coff) & 3) == 0 && !p.out_nchw;
     int act = p.act;
-    if (p.addend) {                                        // out = act(z) + addend: the other consumer's gradient of a tensor used twice
+    // out = act(z) + addend: the other consumer's gradient of a tensor used twice (ops.GradFork)
+    if constexpr (sizeof(T) == 2 && NT % 2 == 0) {
+        // 16-bit NHWC, both 16-channel blocks of a pair inside N and 16-byte aligned: a lane holds 4 channels (8 B) of blocks a and b;
+        // one v_permlane16_swap per dword trades block b of the even 16-lane rows for block a of the odd rows, so that every lane
+        // ends up with 8 consecutive channels of ONE block -> one 16-byte store per pair instead of two 8-byte ones (half the store
+        // instructions, 64-byte instead of 32-byte segments per pixel).  The addend is fetched the same way — one 16-byte load at the
+        // lane's store address — and taken back to the accumulator layout by the same swap (it is its own inverse), so the sum is
+        // formed in fp32 and rounded once (8-byte loads at the accumulator positions cost +39 us on the 64x64 1x1 input gradient).
+        const bool wide = vec_ok && ((p.ldc | p.coff) & 7) == 0 && n0 + wn * (BN / 2) + NT * 16 <= p.N && ((uintptr_t)p.out & 15) == 0 &&
+                          ((uintptr_t)p.addend & 15) == 0;
+        if (wide) {                                        // workgroup-uniform
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                for (int pr = 0; pr < NT / 2; ++pr) {
+                    typedef typename V16<T>::x2 t2;
+                    const int blk = 2 * pr + (fg & 1);     // even 16-lane rows store block a, odd rows block b
+                    const int nb8 = n0 + wn * (BN / 2) + blk * 16 + (fg >> 1) * 8;
+                    float ada[4] = {0.f, 0.f, 0.f, 0.f}, adb[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (p.addend) {                        // uniform
+                        u32x4 qd = {0u, 0u, 0u, 0u};
+                        if (m_ok[mt]) qd = *(const u32x4*)((const T*)p.addend + orow[mt] * p.ldc + p.coff + nb8);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const auto sw = __builtin_amdgcn_permlane16_swap(qd[h], qd[2 + h], false, false);
+                            const t2 a2 = __builtin_bit_cast(t2, (unsigned)sw[0]), b2 = __builtin_bit_cast(t2, (unsigned)sw[1]);
+                            ada[2 * h] = (float)a2[0]; ada[2 * h + 1] = (float)a2[1];
+                            adb[2 * h] = (float)b2[0]; adb[2 * h + 1] = (float)b2[1];
+                        }
+                    }
+                    unsigned qa[2], qb[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const t2 a2 = {(T)(act_apply_t<T>(acc[2 * pr][mt][2 * h], act) + ada[2 * h]), (T)(act_apply_t<T>(acc[2 * pr][mt][2 * h + 1], act) + ada[2 * h + 1])};
+                        const t2 b2 = {(T)(act_apply_t<T>(acc[2 * pr + 1][mt][2 * h], act) + adb[2 * h]), (T)(act_apply_t<T>(acc[2 * pr + 1][mt][2 * h + 1], act) + adb[2 * h + 1])};
+                        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a2), __builtin_bit_cast(unsigned, b2), false, false);
+                        qa[h] = sw[0];                     // even rows: own a      | odd rows: partner's b
+                        qb[h] = sw[1];                     // even rows: partner's a | odd rows: own b
+                    }
+                    if (!m_ok[mt]) continue;
+                    T* o = (T*)p.out + orow[mt] * p.ldc + p.coff + nb8;
+                    *(u32x4*)o = (u32x4){qa[0], qa[1], qb[0], qb[1]};
+                }
+            }
+            return;
+        }
+    }
+    if (p.addend) {                                        // narrow paths: the addend at the accumulator positions
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             if (!m_ok[mt]) continue;
@@ -251,37 +298,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 
             }
         }
         act = DM_ACT_NONE;
-    }
-    if constexpr (sizeof(T) == 2 && NT % 2 == 0) {
-        // bf16 NHWC, both 16-channel blocks of a pair inside N and 16-byte aligned: a lane holds 4 channels (8 B) of blocks a and b;
-        // one v_permlane16_swap per dword trades block b of the even 16-lane rows for block a of the odd rows, so that every lane
-        // ends up with 8 consecutive channels of ONE block -> one 16-byte store per pair instead of two 8-byte ones (half the store
-        // instructions, 64-byte instead of 32-byte segments per pixel)
-        const bool wide = vec_ok && ((p.ldc | p.coff) & 7) == 0 && n0 + wn * (BN / 2) + NT * 16 <= p.N && ((uintptr_t)p.out & 15) == 0;
-        if (wide) {                                        // workgroup-uniform
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-                for (int pr = 0; pr < NT / 2; ++pr) {
-                    unsigned qa[2], qb[2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        typedef typename V16<T>::x2 t2;
-                        const t2 a2 = {(T)act_apply_t<T>(acc[2 * pr][mt][2 * h], act), (T)act_apply_t<T>(acc[2 * pr][mt][2 * h + 1], act)};
-                        const t2 b2 = {(T)act_apply_t<T>(acc[2 * pr + 1][mt][2 * h], act), (T)act_apply_t<T>(acc[2 * pr + 1][mt][2 * h + 1], act)};
-                        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a2), __builtin_bit_cast(unsigned, b2), false, false);
-                        qa[h] = sw[0];                     // even rows: own a      | odd rows: partner's b
-                        qb[h] = sw[1];                     // even rows: partner's a | odd rows: own b
-                    }
-                    if (!m_ok[mt]) continue;
-                    const int blk = 2 * pr + (fg & 1);     // even 16-lane rows store block a, odd rows block b
-                    const int nb8 = n0 + wn * (BN / 2) + blk * 16 + (fg >> 1) * 8;
-                    T* o = (T*)p.out + orow[mt] * p.ldc + p.coff + nb8;
-                    *(u32x4*)o = (u32x4){qa[0], qa[1], qb[0], qb[1]};
-                }
-            }
-            return;
-        }
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -787,6 +803,60 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
 }
 
 // =================================================================================================
+// v7: pointwise (1x1) convolution with a short reduction — operands straight from global memory
+// =================================================================================================
+// The 1x1 layers of UnetDown (channel_compress C -> C/4, ch_adjust C/4 -> Cout: new_scripy.py:217-222) and their input gradients reduce
+// over 32 ... 128 channels only: one or two k-steps per 128-pixel tile.  On the gather kernel a workgroup then spends its life in
+// latency (DMA -> wait -> 1-2 k-steps -> epilogue), two workgroups per CU keep < 32 KiB in flight, and the layers ran at 1.1-2.9 TB/s
+// of the ~4.5 TB/s they are worth (they are pure HBM streaming: 84 MB per launch at 64x64).  Here nothing is staged: every lane loads
+// its MFMA fragments directly — a pixel fragment is 16 pixels x 64 contiguous bytes of their channel rows, a weight fragment
+// 16 rows of the (L2-resident) weight matrix — all of a tile's loads are issued up front (4 waves x up to 32 KiB in flight per
+// workgroup, 2-4 workgroups per CU: no LDS, 110-200 VGPRs), the compiler's own s_waitcnt orders them, and the tile goes through the
+// ordinary epilogue (bias / BatchNorm statistics / addend / 16-byte stores).  K in {32, 64, 128} (KS = K / 32 sub-steps).
+template <typename T, int BN, int KS>
+__global__ __launch_bounds__(256) void conv_pw_kernel(const ConvP p) {
+    constexpr int NT = BN / 32;
+    __shared__ __attribute__((aligned(16))) char smem[4 * BN * 4];       // statistics fold of the epilogue
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1, fr = lane & 15, fg = lane >> 4;
+    const int nb_n = (p.N + BN - 1) / BN;
+    const int bid = remap_xcd(blockIdx.x, gridDim.x);
+    const int mb = bid / nb_n, nb = bid - mb * nb_n;
+    const int m0 = mb * BM, n0 = nb * BN;
+    const int K = p.C1;
+    const T* x = (const T*)p.in1;
+    const T* w = (const T*)p.w;
+    u32x4 fb[KS][4], fa[KS][NT];
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wm * 64 + mt * 16 + fr;
+        const T* row = x + (size_t)(m < p.M ? m : 0) * K + fg * 8;
+#pragma unroll
+        for (int sk = 0; sk < KS; ++sk) fb[sk][mt] = m < p.M ? *(const u32x4*)(row + sk * 32) : zero;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + wn * (BN / 2) + nt * 16 + fr;
+        const T* row = w + (size_t)(n < p.N ? n : 0) * p.ldw + fg * 8;
+#pragma unroll
+        for (int sk = 0; sk < KS; ++sk) fa[sk][nt] = n < p.N ? *(const u32x4*)(row + sk * 32) : zero;
+    }
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sk = 0; sk < KS; ++sk)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) Mma<T>::run(fa[sk][nt], fb[sk][mt], acc[nt][mt]);
+    conv_epilogue<T, BN>(p, acc, smem, tid, wm, wn, fr, fg, mb, m0, n0);
+}
+
+// =================================================================================================
 // v6: halo-resident kernel for FOUR-tap layers: the 4x4 stride-2 convolution and its input gradient
 // =================================================================================================
 // A 4x4 / stride 2 / pad 1 convolution (new_scripy.py:229, UnetDown.down[4]) re-reads every input pixel for 4 of its 16 taps; on the
@@ -1166,9 +1236,35 @@ int launch_tap4_tw(const ConvP& p, hipStream_t st) {
     return launch_tap4<T, 8, S2>(p, st);
 }
 
+int g_pw = 1;
+// a 1x1 stride-1 convolution over one source with 32 / 64 / 128 reduction channels
+bool pw_eligible(const ConvP& p) {
+    if (!g_pw || p.T != 1 || p.sy != 1 || p.sx != 1 || p.C2 != 0 || p.B2 != p.B) return false;
+    if (p.C1 != 32 && p.C1 != 64 && p.C1 != 128) return false;
+    if (p.Hi != p.Hq || p.Wi != p.Wq || p.oy0 != 0 || p.ox0 != 0 || p.N < 32) return false;
+    if (((uintptr_t)p.in1 & 15) || ((uintptr_t)p.w & 15) || (p.ldw & 7)) return false;
+    return true;
+}
+
+template <typename T, int BN>
+int launch_pw(const ConvP& p, hipStream_t st) {
+    const int64_t grid = (int64_t)cdiv(p.M, BM) * cdiv(p.N, BN);
+    if (p.C1 == 32) hipLaunchKernelGGL((conv_pw_kernel<T, BN, 1>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    else if (p.C1 == 64) hipLaunchKernelGGL((conv_pw_kernel<T, BN, 2>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_pw_kernel<T, BN, 4>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    DM_LAUNCH_CHECK();
+    g_last_path = 3;
+    return DM_OK;
+}
+
 template <typename T>
 int launch_conv(const ConvP& p, bool small_offsets, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
+        if (g_variant == 5 && small_offsets && pw_eligible(p)) {
+            if (p.N <= 32) return launch_pw<T, 32>(p, st);
+            if (p.N <= 64) return launch_pw<T, 64>(p, st);
+            return launch_pw<T, 128>(p, st);
+        }
         if (g_variant == 5 && small_offsets) {
             const int m4 = tap4_mode(p);
             if (m4 == 1) return launch_tap4_tw<T, true>(p, st);
@@ -1223,7 +1319,7 @@ int launch_conv(const ConvP& p, bool small_offsets, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int dm_set_conv_tap4(int on) { g_tap4 = on != 0; return DM_OK; }
+extern "C" int dm_set_conv_tap4(int on) { g_tap4 = (on & 1) != 0; g_pw = (on & 2) == 0; return DM_OK; }   // bit 1 set: pointwise kernel off too
 extern "C" int dm_set_splitk_inkernel(int on) { g_splitk_inkernel = on != 0; return DM_OK; }
 
 extern "C" int dm_set_conv_variant(int variant) {

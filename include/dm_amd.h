@@ -98,7 +98,8 @@ int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream);
 int dm_set_wgrad_variant(int variant);
 /* 1 when the last dm_conv_wgrad launch used the halo-resident 3x3 kernel, 0 for the per-tap kernels (measurement aid) */
 int dm_last_wgrad_path(void);
-/* 0: keep the 4x4 / stride-2 convolution and its input gradient on the gather kernel (default 1: conv_tap4_halo_kernel) */
+/* bit 0: the 4x4 / stride-2 convolution and its input gradient on conv_tap4_halo_kernel (default on; 0 = gather kernel);
+   bit 1: set = the short-K 1x1 layers stay on the gather kernel too (default: conv_pw_kernel).  Measurement knob. */
 int dm_set_conv_tap4(int on);
 /* halo kernels with the channel chunks split over workgroups: 0 (default) a separate epilogue launch folds the partials; 1 the last
    split to arrive folds them and runs the epilogue in the same launch (arrival counters at the tail of the workspace) — measured

@@ -706,3 +706,79 @@ def test_splitk_last_arriver_form_is_bit_exact_too():
                 assert torch.equal(nchw(y), yr)
     finally:
         assert lib.dm_set_splitk_inkernel(0) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("k,B,C,N,H", [(3, 2, 64, 128, 32), (1, 2, 32, 128, 16), (3, 1, 64, 72, 16), (1, 3, 64, 40, 8)])
+def test_conv_epilogue_addend_exact_integers(dtype, k, B, C, N, H):
+    """DmConv.addend (the gradient of a tensor with two consumers, ops.GradFork): out = conv(x) + addend, exact on small integers —
+    the halo kernel and the gather kernel, the 16-byte store path (addend fetched at the store address and swapped back to the
+    accumulator layout) and the narrow paths (ragged N, fp32)."""
+    o = ops()
+    g = torch.Generator().manual_seed(k * 100 + C + N)
+    ri = lambda *s: torch.randint(-2, 3, s, generator=g).float()
+    x, w, add = ri(B, C, H, H), ri(N, C, k, k) * (torch.rand(N, C, k, k, generator=g) < 0.2).float(), ri(B, N, H, H) * 3
+    ref = F.conv2d(x, w, None, padding=k // 2) + add
+    assert ref.abs().max() < 256
+    xd, ad = nhwc(x, dtype), nhwc(add, dtype)
+    wp = o.packed_fwd(Holder(w, None).weight, dtype, C)
+    out = torch.empty(B, H, H, N, dtype=dtype, device=DEV)
+    o._conv_call(xd, None, wp.data_ptr(), k * k * C, out, dtype=dtype, B=B, Hi=H, Wi=H, C1=C, C2=0, Hq=H, Wq=H, sy=1, sx=1, T=k * k, KW=k, ty=1, tx=1,
+                 oy0=-(k // 2), ox0=-(k // 2), Ho=H, Wo=H, N=N, addend=ad)
+    assert torch.equal(nchw(out), ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,C,N,H", [(2, 32, 128, 16), (1, 64, 64, 12), (2, 128, 32, 8), (3, 128, 256, 10), (1, 32, 40, 9), (2, 64, 136, 16)])
+def test_pointwise_conv_kernel_exact_integers(dtype, B, C, N, H):
+    """conv_pw_kernel (1x1, K in {32, 64, 128}: fragments straight from global memory) forward and — through the transposed pack —
+    as the input gradient of a 1x1 layer whose output width is 32 / 64 / 128; ragged M (72 .. 300 rows) and N; bit-exact on integers."""
+    o = ops()
+    from diffusionmodel_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 1000 + C + N)
+    ri = lambda *s: torch.randint(-2, 3, s, generator=g).float()
+    x, w, b, probe = ri(B, C, H, H), ri(N, C, 1, 1), ri(N), ri(B, N, H, H)
+    w = w * (torch.rand(N, C, 1, 1, generator=g) < 0.5).float()
+    probe = probe * (torch.rand(B, N, H, H, generator=g) < 0.3).float()
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br)
+    assert yr.abs().max() < 256
+    (yr * probe).sum().backward()
+    assert xr.grad.abs().max() < 256
+    conv = Holder(w, b)
+    xd = nhwc(x, dtype).requires_grad_(True)
+    y = o.conv_bn_act(xd, None, conv, None, o.ConvSpec(1, 1, 1, 0))
+    assert lib.dm_last_conv_path() == 3, "the forward launch did not take the pointwise kernel"
+    assert torch.equal(nchw(y), yr.detach())
+    (y.float() * nhwc(probe)).sum().backward()
+    assert torch.equal(nchw(xd.grad), xr.grad)
+    assert torch.equal(conv.weight.grad.cpu(), wr.grad)
+    assert torch.equal(conv.bias.grad.cpu(), br.grad)
+
+
+def test_pointwise_conv_kernel_batchnorm_statistics():
+    """Train-mode BatchNorm behind the pointwise kernel (UnetDown.channel_compress at n_feat = 128: 128 -> 32 channels + BN + GELU)."""
+    o = ops()
+    torch.manual_seed(0)
+    B, Ci, Co, H = 4, 128, 32, 16
+    x = torch.randn(B, Ci, H, H).bfloat16().float()
+    conv_r = torch.nn.Conv2d(Ci, Co, 1)
+    with torch.no_grad():
+        conv_r.weight.copy_(conv_r.weight.bfloat16().float())
+    bn_r, bn_d = torch.nn.BatchNorm2d(Co), torch.nn.BatchNorm2d(Co).to(DEV)
+    with torch.no_grad():
+        bn_r.weight.uniform_(0.5, 1.5); bn_r.bias.uniform_(-0.3, 0.3)
+    bn_d.load_state_dict(bn_r.state_dict())
+    conv_d = Holder(conv_r.weight.detach().clone(), conv_r.bias.detach().clone())
+    xr = x.clone().requires_grad_(True)
+    yr = F.gelu(bn_r(conv_r(xr)))
+    probe = torch.randn_like(yr)
+    (yr * probe).sum().backward()
+    xd = nhwc(x, torch.bfloat16).requires_grad_(True)
+    y = o.conv_bn_act(xd, None, conv_d, bn_d, o.ConvSpec(1, 1, 1, 0, o.ACT_GELU, bn_d))
+    assert rel_err(nchw(y), yr.detach()) < 1e-2
+    assert rel_err(bn_d.running_mean.cpu(), bn_r.running_mean) < 1e-2 and rel_err(bn_d.running_var.cpu(), bn_r.running_var) < 1e-2
+    (y.float() * nhwc(probe)).sum().backward()
+    assert rel_err(nchw(xd.grad), xr.grad) < 1.5e-2
+    assert rel_err(conv_d.weight.grad.cpu(), conv_r.weight.grad) < 1.5e-2
