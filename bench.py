@@ -274,7 +274,7 @@ def main():
     ap.add_argument("--sample-steps", dest="sample_steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
     ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=8)
-    ap.add_argument("--cpu-iters", dest="cpu_iters", type=int, default=3)
+    ap.add_argument("--cpu-iters", dest="cpu_iters", type=int, default=12)
     ap.add_argument("--launch-selftest", dest="launch_selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one rank per GPU).  gloo is a REHEARSAL mode: the ranks may share devices (rank r uses device "
