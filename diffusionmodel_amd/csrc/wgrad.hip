@@ -395,6 +395,127 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgP p) {
 }
 
 // =================================================================================================
+// v4: weight gradient of the 1x1 layers (bf16 / fp16)
+// =================================================================================================
+// dw[n][c] = sum_m dy[m][n] * in[m][c] with one of N, C at most 128: 1-4 MFLOP per KiB read, so the launch is a stream of
+// dy and the input through the chip (17 us of HBM time for the 64^2 layers at n_feat = 128) and the per-tap kernel above
+// spends it on 128 x 128 tiles that are 75 % padding at C = 32.  Here a 256-thread workgroup owns an output block
+// [BIG = 64*NTW channels of the wider operand] x [SMALL = 16*CTW = ALL channels of the narrower one] and walks over PX-pixel
+// chunks of its pixel range: 16-byte global loads into registers (8-10 per thread, issued one chunk ahead), ds_write_b128
+// into two [pixel][channel] images whose rows are padded by 32 B (the 8 rows a 32-lane half of ds_read_b64_tr_b16 touches
+// then fall on disjoint banks for any row width), transposed fragment reads as in the kernels above, NTW x CTW MFMAs per
+// wave per 32 pixels.  <= 49 KiB of LDS: up to three workgroups per CU.  Wave w takes the wider operand's tiles
+// [w*NTW, (w+1)*NTW).  SWAP says which operand is the wide one: false = dy (wide N, rows of dw), true = the input (wide C,
+// columns of dw) — then the MFMA operands trade places, so that the 16 lanes of a result row always hold 16 consecutive
+// floats of a dw row.  The pixel splits meet in dw through fp32 atomics like the per-tap kernel (which also makes the
+// launch accumulate into dw); measured: ~400 G atomics/s when a wave instruction covers whole 64-byte runs, 65 G/s when
+// its lanes are a row apart (the first version of the SWAP case), so the split count is what the launch pays for: the
+// workgroup count is chosen for a fixed volume of atomics (384 workgroups of 4096 floats, 96 of 16384).
+struct WgPwP {
+    const char* big; const char* small; float* dw; float* dbias;
+    int M, ld_big, ld_small, ldw;     // row strides in elements
+    int nblocks, splits, chunks_per_split, nchunks, swap;
+};
+
+template <typename T, int NTW, int CTW, bool SWAP>
+__global__ __launch_bounds__(256) void wgrad_pw_kernel(const WgPwP p) {
+    constexpr int BIG = 64 * NTW, SMALL = 16 * CTW;
+    constexpr int PX = (BIG + SMALL) <= 160 ? 128 : 64;
+    constexpr int SB = BIG * 2 + 32, SS = SMALL * 2 + 32;       // padded row strides in bytes
+    constexpr int VB = BIG / 8, VS = SMALL / 8;                 // 16-byte vectors per row
+    constexpr int NVB = PX * VB / 256, NVS = PX * VS / 256;     // vectors per thread per chunk
+    static_assert(PX * VB % 256 == 0 && PX * VS % 256 == 0, "whole passes of the 256 threads");
+    __shared__ __attribute__((aligned(16))) char smem[PX * (SB + SS)];
+    char* const img_b = smem;
+    char* const img_s = smem + PX * SB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = blockIdx.x % p.nblocks, sp = blockIdx.x / p.nblocks;
+    const char* gb = p.big + (size_t)blk * BIG * 2;
+    const char* gs = p.small;
+    const int ch_lo = sp * p.chunks_per_split;
+    const int ch_hi = min(ch_lo + p.chunks_per_split, p.nchunks);
+
+    uint4 rb[NVB], rs[NVS];
+    auto fetch = [&](int chunk) {
+        const int m0 = chunk * PX;
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int v = tid + i * 256, row = v / VB, col = v % VB, m = m0 + row;
+            rb[i] = m < p.M ? *(const uint4*)(gb + ((size_t)m * p.ld_big + col * 8) * 2) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NVS; ++i) {
+            const int v = tid + i * 256, row = v / VS, col = v % VS, m = m0 + row;
+            rs[i] = m < p.M ? *(const uint4*)(gs + ((size_t)m * p.ld_small + col * 8) * 2) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int v = tid + i * 256, row = v / VB, col = v % VB;
+            *(uint4*)(img_b + row * SB + col * 16) = rb[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NVS; ++i) {
+            const int v = tid + i * 256, row = v / VS, col = v % VS;
+            *(uint4*)(img_s + row * SS + col * 16) = rs[i];
+        }
+    };
+
+    f32x4 acc[NTW][CTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int j = 0; j < CTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // dbias = column sums of the dy image: every block when dy is the wide operand, block 0 when it is the narrow one
+    constexpr int dy_ch = SWAP ? SMALL : BIG;
+    const bool do_bias = p.dbias != nullptr && tid < dy_ch && (!SWAP || blk == 0);
+    const char* bias_col = (SWAP ? img_s : img_b) + tid * 2;
+    constexpr int bias_stride = SWAP ? SS : SB;
+    float bias_acc = 0.f;
+
+    if (ch_lo < ch_hi) fetch(ch_lo);
+    for (int ch = ch_lo; ch < ch_hi; ++ch) {
+        stash();                                   // waits for the chunk's loads
+        __syncthreads();
+        if (ch + 1 < ch_hi) fetch(ch + 1);         // in flight under the MFMAs and the next barrier
+#pragma unroll
+        for (int ks = 0; ks < PX / 32; ++ks) {
+            bf16x8 fa[NTW], fb[CTW];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) fa[i] = tr_frag(img_b + ks * 32 * SB, SB, (wave * NTW + i) * 16, lane);
+#pragma unroll
+            for (int j = 0; j < CTW; ++j) fb[j] = tr_frag(img_s + ks * 32 * SS, SS, j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                for (int j = 0; j < CTW; ++j)      // rows of the MFMA result = dy channels n, columns = input channels c, either way
+                    acc[i][j] = SWAP ? WMma<T>::run(fb[j], fa[i], acc[i][j]) : WMma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+        if (do_bias) {
+#pragma unroll 8
+            for (int r = 0; r < PX; ++r) bias_acc += Elem<T>::ld((const T*)(bias_col + r * bias_stride));
+        }
+        __syncthreads();                           // every wave is done with the images
+    }
+
+    const int g = lane >> 4, il = lane & 15;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int j = 0; j < CTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {          // 16 lanes -> 16 consecutive floats of one dw row
+                const int bt = blk * BIG + (wave * NTW + i) * 16, st = j * 16;
+                const size_t at = SWAP ? (size_t)(st + 4 * g + r) * p.ldw + bt + il : (size_t)(bt + 4 * g + r) * p.ldw + st + il;
+                atomicAdd(p.dw + at, acc[i][j][r]);
+            }
+    if (do_bias) atomicAdd(p.dbias + (SWAP ? tid : blk * BIG + tid), bias_acc);
+}
+
+// =================================================================================================
 // v3: halo-resident weight gradient of the 3x3 stride-1 layers (bf16)
 // =================================================================================================
 // The kernels above give every (n tile, tap, channel tile) its own workgroups, so the nine taps re-stage
@@ -789,8 +910,65 @@ bool wgrad_halo_plan(const DmWgrad* d, int64_t M, WgHP& hp) {
     return true;
 }
 
-static int g_last_wgrad_path = 0;   // 1: the last dm_conv_wgrad launch went to wgrad3x3_halo_kernel
+int g_wgrad_pw = 1;            // 1x1 layers on wgrad_pw_kernel
+int g_wgrad_pw_blocks = 384;   // workgroups its pixel split aims at when a workgroup's block is 4096 floats; fewer for larger blocks (same atomic traffic)
+int g_wgrad_pw_min_m = 0;      // pixels below which the per-tap kernel keeps the launch
+
+// 16-bit 1x1 stride-1 layer, one source, identity pixel mapping, min(N, C) in {32, 64, 128} and the wider side a whole number of blocks
+bool wgrad_pw_plan(const DmWgrad* d, int64_t M, WgPwP& q, int& ntw, int& ctw) {
+    if (!g_wgrad_pw || d->dtype == DM_F32 || d->T != 1 || d->KW != 1 || d->sy != 1 || d->sx != 1 || d->oy0 != 0 || d->ox0 != 0 || d->C2 != 0) return false;
+    if (d->Hq != d->Hi || d->Wq != d->Wi || d->Ho != d->Hq || d->Wo != d->Wq || d->osy != 1 || d->osx != 1 || d->ooy != 0 || d->oox != 0) return false;
+    if (((uintptr_t)d->dy & 15) || ((uintptr_t)d->in1 & 15) || d->ldy % 8 != 0 || d->splitk > 0) return false;
+    const int N = d->N, C = d->C1;
+    const int small = N < C ? N : C, big = N < C ? C : N;
+    if (small == 32 && big % 256 == 0) { ntw = 4; ctw = 2; }
+    else if (small == 32 && big % 128 == 0) { ntw = 2; ctw = 2; }
+    else if (small == 64 && big % 256 == 0) { ntw = 4; ctw = 4; }
+    else if (small == 128 && big % 128 == 0) { ntw = 2; ctw = 8; }
+    else return false;
+    if (M * (int64_t)(d->ldy > C ? d->ldy : C) * 2 >= (1ll << 32) || M < g_wgrad_pw_min_m) return false;
+    const int BIG = 64 * ntw, PX = (BIG + 16 * ctw) <= 160 ? 128 : 64;
+    q.swap = N < C ? 1 : 0;                       // N == C (128 x 128): dy is the wide operand
+    q.big = (const char*)(q.swap ? d->in1 : d->dy);
+    q.small = (const char*)(q.swap ? d->dy : d->in1);
+    q.ld_big = q.swap ? C : d->ldy;
+    q.ld_small = q.swap ? d->ldy : C;
+    q.dw = d->dw; q.dbias = d->dbias; q.M = (int)M; q.ldw = d->ldw;
+    q.nblocks = big / BIG;
+    q.nchunks = (int)((M + PX - 1) / PX);
+    int splits = (int)((int64_t)g_wgrad_pw_blocks * 4096 / (BIG * 16 * ctw)) / q.nblocks;
+    if (splits > q.nchunks / 2) splits = q.nchunks / 2;      // at least two chunks per workgroup: the second is fetched under the first
+    if (splits < 1) splits = 1;
+    q.chunks_per_split = cdiv(q.nchunks, splits);
+    q.splits = cdiv(q.nchunks, q.chunks_per_split);
+    return true;
+}
+
+template <typename T>
+int launch_wgrad_pw(const WgPwP& q, int ntw, int ctw, hipStream_t st) {
+    const dim3 grid((unsigned)(q.nblocks * q.splits));
+#define DM_WGPW(A, B_) \
+    if (q.swap) hipLaunchKernelGGL((wgrad_pw_kernel<T, A, B_, true>), grid, dim3(256), 0, st, q); \
+    else hipLaunchKernelGGL((wgrad_pw_kernel<T, A, B_, false>), grid, dim3(256), 0, st, q)
+    if (ntw == 2 && ctw == 2) { DM_WGPW(2, 2); }
+    else if (ntw == 4 && ctw == 2) { DM_WGPW(4, 2); }
+    else if (ntw == 4 && ctw == 4) { DM_WGPW(4, 4); }
+    else { DM_WGPW(2, 8); }
+#undef DM_WGPW
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+static int g_last_wgrad_path = 0;   // 1: the last dm_conv_wgrad launch went to wgrad3x3_halo_kernel, 2: to wgrad_pw_kernel
 extern "C" int dm_last_wgrad_path(void) { return g_last_wgrad_path; }
+
+extern "C" int dm_set_wgrad_pw(int enable, int target_blocks, int min_pixels) {
+    DM_CHECK_ARG(target_blocks >= 0 && target_blocks <= 65536, "dm_set_wgrad_pw: target_blocks %d out of range", target_blocks);
+    g_wgrad_pw = enable != 0;
+    if (target_blocks > 0) g_wgrad_pw_blocks = target_blocks;
+    if (min_pixels >= 0) g_wgrad_pw_min_m = min_pixels;
+    return DM_OK;
+}
 
 extern "C" int dm_set_wgrad_variant(int variant) {
     // variant >= 64 sets the workgroup target of the pixel split instead (tuning)
@@ -830,6 +1008,12 @@ extern "C" int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream) {
         if (d->Wi == 32) return launch_wgrad_halo<bf16, 32>(hp, hst);
         if (d->Wi == 16) return launch_wgrad_halo<bf16, 16>(hp, hst);
         return launch_wgrad_halo<bf16, 8>(hp, hst);
+    }
+    WgPwP q;
+    int ntw = 0, ctw = 0;
+    if (wgrad_pw_plan(d, M, q, ntw, ctw)) {
+        g_last_wgrad_path = 2;
+        return d->dtype == DM_F16 ? launch_wgrad_pw<f16>(q, ntw, ctw, (hipStream_t)stream) : launch_wgrad_pw<bf16>(q, ntw, ctw, (hipStream_t)stream);
     }
     WgP p;
     p.dy = (const char*)d->dy; p.in1 = (const char*)d->in1; p.in2 = (const char*)d->in2; p.dw = d->dw; p.dbias = d->dbias;

@@ -782,3 +782,49 @@ def test_pointwise_conv_kernel_batchnorm_statistics():
     (y.float() * nhwc(probe)).sum().backward()
     assert rel_err(nchw(xd.grad), xr.grad) < 1.5e-2
     assert rel_err(conv_d.weight.grad.cpu(), conv_r.weight.grad) < 1.5e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,C,N,H", [
+    (2, 32, 128, 16), (3, 128, 32, 10),          # 128 x 32 block, 128-pixel chunks; the second with the input as the wide operand and a ragged last chunk
+    (4, 32, 256, 32), (1, 256, 32, 9),           # 256 x 32
+    (2, 64, 512, 16), (3, 256, 64, 8),           # 256 x 64 blocks (two along N / one along C)
+    (2, 128, 128, 16), (1, 128, 384, 12), (3, 512, 128, 8),   # 128 x 128 blocks: square, three along N, four along C
+])
+def test_pointwise_wgrad_kernel_exact_integers(dtype, B, C, N, H):
+    """wgrad_pw_kernel (weight gradient of the 1x1 layers: one of N, C in {32, 64, 128}, the other in whole blocks): every block
+    shape with either operand as the wide one, several pixel splits meeting through the atomics, ragged last chunks (81 .. 300
+    rows), bias gradient from either image; bit-exact on integers."""
+    o = ops()
+    from diffusionmodel_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 1000 + C + N)
+    ri = lambda *s: torch.randint(-2, 3, s, generator=g).float()
+    x, w, b, probe = ri(B, C, H, H), ri(N, C, 1, 1), ri(N), ri(B, N, H, H)
+    w = w * (torch.rand(N, C, 1, 1, generator=g) < 0.1).float()
+    probe = probe * (torch.rand(B, N, H, H, generator=g) < 0.3).float()
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br)
+    assert yr.abs().max() < 256
+    (yr * probe).sum().backward()
+    assert xr.grad.abs().max() < 256
+    conv = Holder(w, b)
+    xd = nhwc(x, dtype).requires_grad_(True)
+    y = o.conv_bn_act(xd, None, conv, None, o.ConvSpec(1, 1, 1, 0))
+    assert torch.equal(nchw(y), yr.detach())
+    try:
+        (y.float() * nhwc(probe)).sum().backward()
+        assert lib.dm_last_wgrad_path() == 2, "the weight gradient did not take the 1x1 kernel"
+        assert torch.equal(conv.weight.grad.cpu(), wr.grad)
+        assert torch.equal(conv.bias.grad.cpu(), br.grad)
+        assert torch.equal(nchw(xd.grad), xr.grad)
+        for knob in ((1, 96, 0), (0, 0, 0)):          # same result from a different split count (96 workgroups) and from the per-tap kernel
+            assert lib.dm_set_wgrad_pw(*knob) == 0
+            conv.weight.grad = None
+            conv.bias.grad = None
+            y = o.conv_bn_act(nhwc(x, dtype).requires_grad_(True), None, conv, None, o.ConvSpec(1, 1, 1, 0))
+            (y.float() * nhwc(probe)).sum().backward()
+            assert lib.dm_last_wgrad_path() == (2 if knob[0] else 0)
+            assert torch.equal(conv.weight.grad.cpu(), wr.grad)
+    finally:
+        assert lib.dm_set_wgrad_pw(1, 384, 0) == 0
