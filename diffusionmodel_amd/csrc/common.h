@@ -13,6 +13,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
@@ -94,6 +95,21 @@ __device__ inline void gelu_parts_fast(float x, float& cdf, float& e) {
     e = __expf(-z * z);
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     cdf = 0.5f * (1.0f + copysignf(1.0f - poly * e, x));
+}
+// Two evaluations side by side: the polynomial and the affine steps run on v_pk_fma_f32 / v_pk_mul_f32 (two results per issue
+// slot), v_rcp_f32 / v_exp_f32 stay one per element.  The BN + GELU streaming kernels are VALU-bound in 16-bit mode (33.5 M elements
+// x ~30 issue slots against 4 SIMDs x 256 CUs = 30 us on a 64x64x128 layer that streams in 25 us): this is what brings them back
+// under the HBM time.  Same formula as gelu_parts_fast.
+__device__ inline void gelu_parts_fast2(const f32x2 x, f32x2& cdf, f32x2& e) {
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2 d = ax * (0.3275911f * 0.70710678118654752440f) + 1.0f;
+    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const f32x2 a = (x * x) * (-0.5f * 1.4426950408889634f);               // exp(-x^2 / 2) = exp2(-x^2 / 2 * log2 e)
+    e = (f32x2){__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+    const f32x2 poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const f32x2 q = 1.0f - poly * e;
+    const f32x2 sg = {copysignf(q[0], x[0]), copysignf(q[1], x[1])};
+    cdf = sg * 0.5f + 0.5f;
 }
 template <typename T> __device__ inline float act_apply_t(float x, int act) {
     if constexpr (sizeof(T) == 2) {

@@ -119,6 +119,39 @@ struct BnParams {
     }
 };
 
+// The same constants for the packed 16-bit GELU path (gelu_parts_fast2): xhat = z * rs + nmr, u = xhat * gm + bt on pairs of channels
+struct BnPair {
+    f32x2 rs[4], nmr[4], gm[4], bt[4];
+    __device__ inline void set(const BnParams<8>& P) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            rs[j] = (f32x2){P.rs[2 * j], P.rs[2 * j + 1]};
+            nmr[j] = (f32x2){-P.mu[2 * j] * P.rs[2 * j], -P.mu[2 * j + 1] * P.rs[2 * j + 1]};
+            gm[j] = (f32x2){P.gm[2 * j], P.gm[2 * j + 1]};
+            bt[j] = (f32x2){P.bt[2 * j], P.bt[2 * j + 1]};
+        }
+    }
+    // y = gelu(bn(z)) for the 8 values of a vector
+    __device__ inline void fwd_gelu(float* v) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x2 u = ((f32x2){v[2 * j], v[2 * j + 1]} * rs[j] + nmr[j]) * gm[j] + bt[j];
+            f32x2 cdf, e;
+            gelu_parts_fast2(u, cdf, e);
+            const f32x2 y = u * cdf;
+            v[2 * j] = y[0]; v[2 * j + 1] = y[1];
+        }
+    }
+    // g = dy * gelu'(bn(z)) and xhat for channel pair j
+    __device__ inline void bwd_gelu(int j, const float* zz, const float* dd, f32x2& g, f32x2& xh) const {
+        xh = (f32x2){zz[2 * j], zz[2 * j + 1]} * rs[j] + nmr[j];
+        const f32x2 u = xh * gm[j] + bt[j];
+        f32x2 cdf, e;
+        gelu_parts_fast2(u, cdf, e);
+        g = (f32x2){dd[2 * j], dd[2 * j + 1]} * ((u * e) * 0.39894228040143267794f + cdf);
+    }
+};
+
 // one wave per channel: lanes stride over the partial blocks
 // Column sums over the per-block partial rows (nblk x C, up to 2048 rows on the 64x64 layers).  A 1024-thread workgroup owns
 // 16 columns: thread = (column, one of 64 row lanes), so a 16-lane group reads one 64-byte line per row (a wave-load touches 4
@@ -203,6 +236,20 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* z, T* y, int64
     if (g0 >= G) return;
     BnParams<V> P;
     P.load((int)(g0 % CV) * V, CV * V, mean, rstd, gamma, beta);
+    if constexpr (sizeof(T) == 2 && V == 8) {
+        if (act == DM_ACT_GELU) {                    // packed fp32 math, see gelu_parts_fast2
+            BnPair Q;
+            Q.set(P);
+#pragma unroll 2
+            for (int64_t i = g0; i < nvec; i += G) {
+                float v[V];
+                load_cols<T, V>(z + i * V, v);
+                Q.fwd_gelu(v);
+                store_cols<T, V>(y + i * V, v);
+            }
+            return;
+        }
+    }
 #pragma unroll 2
     for (int64_t i = g0; i < nvec; i += G) {
         float v[V];
@@ -248,6 +295,20 @@ __global__ __launch_bounds__(256) void bn_act_fwd_slots_kernel(const T* z, T* y,
     if (g0 >= G) return;
     BnParams<V> P;
     P.load((int)(g0 % CV) * V, C, sstat, sstat + C, gamma, beta);
+    if constexpr (sizeof(T) == 2 && V == 8) {
+        if (act == DM_ACT_GELU) {                    // packed fp32 math, see gelu_parts_fast2
+            BnPair Q;
+            Q.set(P);
+#pragma unroll 2
+            for (int64_t i = g0; i < nvec; i += G) {
+                float v[V];
+                load_cols<T, V>(z + i * V, v);
+                Q.fwd_gelu(v);
+                store_cols<T, V>(y + i * V, v);
+            }
+            return;
+        }
+    }
 #pragma unroll 2
     for (int64_t i = g0; i < nvec; i += G) {
         float v[V];
@@ -262,11 +323,28 @@ template <typename T, int V>
 struct BwdRedF {
     const T* z; const T* dy; int C; const float* mean; const float* rstd; const float* gamma; const float* beta; int act;
     BnParams<V> P;
-    __device__ inline void init(int c0) { P.load(c0, C, mean, rstd, gamma, beta); }
+    BnPair Q;
+    __device__ inline void init(int c0) {
+        P.load(c0, C, mean, rstd, gamma, beta);
+        if constexpr (sizeof(T) == 2 && V == 8) Q.set(P);
+    }
     __device__ inline void row(int r, int c0, float* v1, float* v2) const {
         float zz[V], dd[V];
         load_cols<T, V>(z + (size_t)r * C + c0, zz);
         load_cols<T, V>(dy + (size_t)r * C + c0, dd);
+        if constexpr (sizeof(T) == 2 && V == 8) {
+            if (act == DM_ACT_GELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x2 g, xh;
+                    Q.bwd_gelu(j, zz, dd, g, xh);
+                    const f32x2 gx = g * xh;
+                    v1[2 * j] = g[0]; v1[2 * j + 1] = g[1];
+                    v2[2 * j] = gx[0]; v2[2 * j + 1] = gx[1];
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const float xh = (zz[i] - P.mu[i]) * P.rs[i];
@@ -297,6 +375,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* z, const T* 
     float m1[V], m2[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) { m1[k] = s1[c0 + k] * invM; m2[k] = s2[c0 + k] * invM; }
+    if constexpr (sizeof(T) == 2 && V == 8) {
+        if (act == DM_ACT_GELU) {                    // packed fp32 math, see gelu_parts_fast2
+            BnPair Q;
+            Q.set(P);
+            f32x2 nm1[4], nm2[4], gr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                nm1[j] = (f32x2){-m1[2 * j], -m1[2 * j + 1]};
+                nm2[j] = (f32x2){-m2[2 * j], -m2[2 * j + 1]};
+                gr[j] = Q.gm[j] * Q.rs[j];
+            }
+#pragma unroll 2
+            for (int64_t i = g0; i < nvec; i += G) {
+                float zz[V], dd[V];
+                load_cols<T, V>(z + i * V, zz);
+                load_cols<T, V>(dy + i * V, dd);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x2 g, xh;
+                    Q.bwd_gelu(j, zz, dd, g, xh);
+                    const f32x2 r = (xh * nm2[j] + (g + nm1[j])) * gr[j];
+                    zz[2 * j] = r[0]; zz[2 * j + 1] = r[1];
+                }
+                store_cols<T, V>(dz + i * V, zz);
+            }
+            return;
+        }
+    }
 #pragma unroll 2
     for (int64_t i = g0; i < nvec; i += G) {
         float zz[V], dd[V];
@@ -337,6 +443,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_slots_kernel(const T* z, con
     float m1[V], m2[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) { m1[k] = ssum[c0 + k] * invM; m2[k] = ssum[C + c0 + k] * invM; }
+    if constexpr (sizeof(T) == 2 && V == 8) {
+        if (act == DM_ACT_GELU) {                    // packed fp32 math, see gelu_parts_fast2
+            BnPair Q;
+            Q.set(P);
+            f32x2 nm1[4], nm2[4], gr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                nm1[j] = (f32x2){-m1[2 * j], -m1[2 * j + 1]};
+                nm2[j] = (f32x2){-m2[2 * j], -m2[2 * j + 1]};
+                gr[j] = Q.gm[j] * Q.rs[j];
+            }
+#pragma unroll 2
+            for (int64_t i = g0; i < nvec; i += G) {
+                float zz[V], dd[V];
+                load_cols<T, V>(z + i * V, zz);
+                load_cols<T, V>(dy + i * V, dd);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x2 g, xh;
+                    Q.bwd_gelu(j, zz, dd, g, xh);
+                    const f32x2 r = (xh * nm2[j] + (g + nm1[j])) * gr[j];
+                    zz[2 * j] = r[0]; zz[2 * j + 1] = r[1];
+                }
+                store_cols<T, V>(dz + i * V, zz);
+            }
+            return;
+        }
+    }
 #pragma unroll 2
     for (int64_t i = g0; i < nvec; i += G) {
         float zz[V], dd[V];

@@ -89,9 +89,17 @@ def test_bf16_benchmark_width_f128_b8_against_fp32_oracle():
         ref = m["oracle_autocast_bf16_grads"]
         worst_norm = max(abs(v["norm_rel_err"]) for v in ref.values())
         worst_cos = max(v["one_minus_cos"] for v in ref.values())
+        # Per child this compares ONE realisation of bf16 rounding noise with another (no fixture averages them at this size): two
+        # builds whose BatchNorm kernels differ only in the order of fp32 operations measured 1.15x and 1.50x on ca1 in eval mode
+        # (0.61 .. 1.12x on the other 18 children, 0.68 .. 0.94x in train mode).  So: 1.6x per child, and the mean ratio over the
+        # children — where the realisations average out — must stay below 1 (measured 0.82 .. 0.88).
+        ratios = []
         for cn, v in m["grads"].items():
             assert abs(v["norm_rel_err"]) <= max(worst_norm, 0.05), (mode, cn, v)
-            assert v["one_minus_cos"] <= MARGIN * max(ref[cn]["one_minus_cos"], 0.1 * worst_cos), (mode, cn, v, ref[cn])
+            assert v["one_minus_cos"] <= 1.6 * max(ref[cn]["one_minus_cos"], 0.1 * worst_cos), (mode, cn, v, ref[cn])
+            ratios.append(v["one_minus_cos"] / max(ref[cn]["one_minus_cos"], 1e-12))
+        print(f"F=128 B=8 bf16 {mode}: per-child (1 - cos) / oracle-autocast: mean {sum(ratios) / len(ratios):.2f}, max {max(ratios):.2f}")
+        assert sum(ratios) / len(ratios) <= 1.0, (mode, ratios)
 
 
 def test_three_optimiser_steps_reproduce_the_reference_loop_fp32():
