@@ -319,46 +319,51 @@ __global__ __launch_bounds__(256) void bn_act_fwd_slots_kernel(const T* z, T* y,
     }
 }
 
-template <typename T, int V>
+// PK: the packed 16-bit GELU path (gelu_parts_fast2) as its own instantiation, so that only one set of channel constants is live
+// in the row loop (with both, the kernel went from < 128 to 136 VGPRs and ran 3 us slower per launch in the train step)
+template <typename T, int V, bool PK>
 struct BwdRedF {
     const T* z; const T* dy; int C; const float* mean; const float* rstd; const float* gamma; const float* beta; int act;
-    BnParams<V> P;
+    BnParams<PK ? 1 : V> P;
     BnPair Q;
     __device__ inline void init(int c0) {
-        P.load(c0, C, mean, rstd, gamma, beta);
-        if constexpr (sizeof(T) == 2 && V == 8) Q.set(P);
+        if constexpr (PK) {
+            BnParams<V> P8;
+            P8.load(c0, C, mean, rstd, gamma, beta);
+            Q.set(P8);
+        } else {
+            P.load(c0, C, mean, rstd, gamma, beta);
+        }
     }
     __device__ inline void row(int r, int c0, float* v1, float* v2) const {
         float zz[V], dd[V];
         load_cols<T, V>(z + (size_t)r * C + c0, zz);
         load_cols<T, V>(dy + (size_t)r * C + c0, dd);
-        if constexpr (sizeof(T) == 2 && V == 8) {
-            if (act == DM_ACT_GELU) {
+        if constexpr (PK) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x2 g, xh;
-                    Q.bwd_gelu(j, zz, dd, g, xh);
-                    const f32x2 gx = g * xh;
-                    v1[2 * j] = g[0]; v1[2 * j + 1] = g[1];
-                    v2[2 * j] = gx[0]; v2[2 * j + 1] = gx[1];
-                }
-                return;
+            for (int j = 0; j < 4; ++j) {
+                f32x2 g, xh;
+                Q.bwd_gelu(j, zz, dd, g, xh);
+                const f32x2 gx = g * xh;
+                v1[2 * j] = g[0]; v1[2 * j + 1] = g[1];
+                v2[2 * j] = gx[0]; v2[2 * j + 1] = gx[1];
             }
-        }
+        } else {
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            const float xh = (zz[i] - P.mu[i]) * P.rs[i];
-            const float g = dd[i] * act_grad_t<T>(xh * P.gm[i] + P.bt[i], act);
-            v1[i] = g;
-            v2[i] = g * xh;
+            for (int i = 0; i < V; ++i) {
+                const float xh = (zz[i] - P.mu[i]) * P.rs[i];
+                const float g = dd[i] * act_grad_t<T>(xh * P.gm[i] + P.bt[i], act);
+                v1[i] = g;
+                v2[i] = g * xh;
+            }
         }
     }
 };
-template <typename T, int V>
+template <typename T, int V, bool PK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* z, const T* dy, int M, int C, const float* mean,
                                                             const float* rstd, const float* gamma, const float* beta,
                                                             int act, int rpb, float* p1, float* p2, int slots) {
-    BwdRedF<T, V> f{z, dy, C, mean, rstd, gamma, beta, act, {}};
+    BwdRedF<T, V, PK> f{z, dy, C, mean, rstd, gamma, beta, act, {}, {}};
     col_partial<V>(M, C, rpb, p1, p2, f, slots);
 }
 
@@ -828,6 +833,7 @@ int stream_grid(int64_t nvec, int cv) {
 
 // rows per workgroup of the column-reduction kernels: small matrices get thinner slabs so that the grid
 // still covers the chip
+int g_bn_packed = getenv("DM_BN_REDUCE_PACKED") ? atoi(getenv("DM_BN_REDUCE_PACKED")) : 1;   // A/B knob for the packed reduce kernel
 int cs_rows(int M) {                                  // ~1024 workgroups: 8 ... 256 rows each (a power of two)
     int r = 8;
     while (r < 256 && (int64_t)r * 2048 <= M) r *= 2;
@@ -901,8 +907,16 @@ extern "C" int dm_bn_act_bwd_reduce(const void* z, const void* dy, int dtype, in
     DM_CHECK_ARG(z && dy && mean && rstd && p1 && p2 && M > 0 && C > 0, "dm_bn_act_bwd_reduce: bad arguments");
     const int rpb = cs_rows(M), grid = cdiv(M, rpb);
     DM_DISPATCH_DTYPE(dtype, {
-        if (vec_ok<T>(C, z, dy)) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, Elem<T>::VE>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2, 0);
-        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2, 0);
+        if (vec_ok<T>(C, z, dy)) {
+            if constexpr (sizeof(T) == 2) {
+                if (act == DM_ACT_GELU && g_bn_packed) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 8, true>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2, 0);
+                else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 8, false>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2, 0);
+            } else {
+                hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, Elem<T>::VE, false>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2, 0);
+            }
+        } else {
+            hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1, false>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2, 0);
+        }
     });
     DM_LAUNCH_CHECK();
     return DM_OK;
@@ -953,8 +967,16 @@ extern "C" int dm_bn_act_bwd_reduce_slots(const void* z, const void* dy, int dty
                  "dm_bn_act_bwd_reduce_slots: bad arguments");
     const int rpb = cs_rows(M), grid = cdiv(M, rpb);
     DM_DISPATCH_DTYPE(dtype, {
-        if (vec_ok<T>(C, z, dy)) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, Elem<T>::VE>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2, slots);
-        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2, slots);
+        if (vec_ok<T>(C, z, dy)) {
+            if constexpr (sizeof(T) == 2) {
+                if (act == DM_ACT_GELU && g_bn_packed) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 8, true>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2, slots);
+                else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 8, false>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2, slots);
+            } else {
+                hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, Elem<T>::VE, false>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2, slots);
+            }
+        } else {
+            hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1, false>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)z, (const T*)dy, M, C, mean, rstd, gamma, beta, act, rpb, p1, p2, slots);
+        }
     });
     DM_LAUNCH_CHECK();
     return DM_OK;
