@@ -158,6 +158,130 @@ __device__ __forceinline__ void mma_stage(const char* sA, const char* sB, int wm
 }
 
 // epilogue: z = acc*scale + shift ; optional per-block column statistics ; activation ; store
+// activation with a compile-time selector (ACTC >= 0) or the runtime value (ACTC < 0)
+template <typename T, int ACTC>
+__device__ __forceinline__ float act_c(float x, int act) {
+    if constexpr (ACTC == DM_ACT_NONE) return x;
+    else if constexpr (ACTC >= 0) return act_apply_t<T>(x, ACTC);
+    else return act_apply_t<T>(x, act);
+}
+
+// second half of the epilogue: activation, addend, stores
+template <typename T, int BN, int ACTC>
+__device__ __forceinline__ void conv_store(const ConvP& p, f32x4 (&acc)[BN / 32][4], const bool (&m_ok)[4], const size_t (&orow)[4], const int (&ob)[4],
+                                           const int (&oy)[4], const int (&ox)[4], int wn, int fg, int n0) {
+    constexpr int NT = BN / 32;
+    const bool vec_ok = ((p.ldc | p.coff) & 3) == 0 && !p.out_nchw;
+    const int act = ACTC >= 0 ? ACTC : p.act;
+    bool applied = false;
+    // out = act(z) + addend: the other consumer's gradient of a tensor used twice (ops.GradFork)
+    if constexpr (sizeof(T) == 2 && NT % 2 == 0) {
+        // 16-bit NHWC, both 16-channel blocks of a pair inside N and 16-byte aligned: a lane holds 4 channels (8 B) of blocks a and b;
+        // one v_permlane16_swap per dword trades block b of the even 16-lane rows for block a of the odd rows, so that every lane
+        // ends up with 8 consecutive channels of ONE block -> one 16-byte store per pair instead of two 8-byte ones (half the store
+        // instructions, 64-byte instead of 32-byte segments per pixel).  The addend is fetched the same way — one 16-byte load at the
+        // lane's store address — and taken back to the accumulator layout by the same swap (it is its own inverse), so the sum is
+        // formed in fp32 and rounded once (8-byte loads at the accumulator positions cost +39 us on the 64x64 1x1 input gradient).
+        const bool wide = vec_ok && ((p.ldc | p.coff) & 7) == 0 && n0 + wn * (BN / 2) + NT * 16 <= p.N && ((uintptr_t)p.out & 15) == 0 &&
+                          ((uintptr_t)p.addend & 15) == 0;
+        if (wide) {                                        // workgroup-uniform
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                for (int pr = 0; pr < NT / 2; ++pr) {
+                    typedef typename V16<T>::x2 t2;
+                    const int blk = 2 * pr + (fg & 1);     // even 16-lane rows store block a, odd rows block b
+                    const int nb8 = n0 + wn * (BN / 2) + blk * 16 + (fg >> 1) * 8;
+                    float ada[4] = {0.f, 0.f, 0.f, 0.f}, adb[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (p.addend) {                        // uniform
+                        u32x4 qd = {0u, 0u, 0u, 0u};
+                        if (m_ok[mt]) qd = *(const u32x4*)((const T*)p.addend + orow[mt] * p.ldc + p.coff + nb8);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const auto sw = __builtin_amdgcn_permlane16_swap(qd[h], qd[2 + h], false, false);
+                            const t2 a2 = __builtin_bit_cast(t2, (unsigned)sw[0]), b2 = __builtin_bit_cast(t2, (unsigned)sw[1]);
+                            ada[2 * h] = (float)a2[0]; ada[2 * h + 1] = (float)a2[1];
+                            adb[2 * h] = (float)b2[0]; adb[2 * h + 1] = (float)b2[1];
+                        }
+                    }
+                    unsigned qa[2], qb[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const t2 a2 = {(T)(act_c<T, ACTC>(acc[2 * pr][mt][2 * h], act) + ada[2 * h]), (T)(act_c<T, ACTC>(acc[2 * pr][mt][2 * h + 1], act) + ada[2 * h + 1])};
+                        const t2 b2 = {(T)(act_c<T, ACTC>(acc[2 * pr + 1][mt][2 * h], act) + adb[2 * h]), (T)(act_c<T, ACTC>(acc[2 * pr + 1][mt][2 * h + 1], act) + adb[2 * h + 1])};
+                        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a2), __builtin_bit_cast(unsigned, b2), false, false);
+                        qa[h] = sw[0];                     // even rows: own a      | odd rows: partner's b
+                        qb[h] = sw[1];                     // even rows: partner's a | odd rows: own b
+                    }
+                    if (!m_ok[mt]) continue;
+                    T* o = (T*)p.out + orow[mt] * p.ldc + p.coff + nb8;
+                    *(u32x4*)o = (u32x4){qa[0], qa[1], qb[0], qb[1]};
+                }
+            }
+            return;
+        }
+    }
+    if (p.addend) {                                        // narrow paths: the addend at the accumulator positions
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            if (!m_ok[mt]) continue;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int nb4 = n0 + wn * (BN / 2) + nt * 16 + fg * 4;
+                const T* a = (const T*)p.addend + orow[mt] * p.ldc + p.coff + nb4;
+                if (vec_ok && nb4 + 3 < p.N) {
+                    if constexpr (sizeof(T) == 4) {
+                        const f32x4 q = *(const f32x4*)a;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[nt][mt][r] = act_c<T, ACTC>(acc[nt][mt][r], act) + q[r];
+                    } else {
+                        const typename V16<T>::x4 q = *(const typename V16<T>::x4*)a;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[nt][mt][r] = act_c<T, ACTC>(acc[nt][mt][r], act) + (float)q[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[nt][mt][r] = act_c<T, ACTC>(acc[nt][mt][r], act) + (nb4 + r < p.N ? Elem<T>::ld(a + r) : 0.f);
+                }
+            }
+        }
+        applied = true;                                    // the activation went in before the addend
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        if (!m_ok[mt]) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int nb4 = n0 + wn * (BN / 2) + nt * 16 + fg * 4;
+            if (nb4 >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = applied ? acc[nt][mt][r] : act_c<T, ACTC>(acc[nt][mt][r], act);
+            if (p.out_nchw) {
+                float* o = (float*)p.out;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (nb4 + r < p.N) o[(((size_t)ob[mt] * p.N + nb4 + r) * p.Ho + oy[mt]) * p.Wo + ox[mt]] = v[r];
+            } else {
+                T* o = (T*)p.out + orow[mt] * p.ldc + p.coff + nb4;
+                if (vec_ok && nb4 + 3 < p.N) {
+                    if constexpr (sizeof(T) == 4) {
+                        *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
+                    } else {
+                        typedef typename V16<T>::x4 t4;
+                        t4 q = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+                        *(t4*)o = q;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nb4 + r < p.N) Elem<T>::st(o + r, v[r]);
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int BN>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 32][4], char* smem, int tid, int wm, int wn, int fr,
                                               int fg, int mb, int m0, int n0) {
@@ -224,114 +348,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 
         }
     }
 
-    const bool vec_ok = ((p.ldc | p.coff) & 3) == 0 && !p.out_nchw;
-    int act = p.act;
-    // out = act(z) + addend: the other consumer's gradient of a tensor used twice (ops.GradFork)
-    if constexpr (sizeof(T) == 2 && NT % 2 == 0) {
-        // 16-bit NHWC, both 16-channel blocks of a pair inside N and 16-byte aligned: a lane holds 4 channels (8 B) of blocks a and b;
-        // one v_permlane16_swap per dword trades block b of the even 16-lane rows for block a of the odd rows, so that every lane
-        // ends up with 8 consecutive channels of ONE block -> one 16-byte store per pair instead of two 8-byte ones (half the store
-        // instructions, 64-byte instead of 32-byte segments per pixel).  The addend is fetched the same way — one 16-byte load at the
-        // lane's store address — and taken back to the accumulator layout by the same swap (it is its own inverse), so the sum is
-        // formed in fp32 and rounded once (8-byte loads at the accumulator positions cost +39 us on the 64x64 1x1 input gradient).
-        const bool wide = vec_ok && ((p.ldc | p.coff) & 7) == 0 && n0 + wn * (BN / 2) + NT * 16 <= p.N && ((uintptr_t)p.out & 15) == 0 &&
-                          ((uintptr_t)p.addend & 15) == 0;
-        if (wide) {                                        // workgroup-uniform
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-                for (int pr = 0; pr < NT / 2; ++pr) {
-                    typedef typename V16<T>::x2 t2;
-                    const int blk = 2 * pr + (fg & 1);     // even 16-lane rows store block a, odd rows block b
-                    const int nb8 = n0 + wn * (BN / 2) + blk * 16 + (fg >> 1) * 8;
-                    float ada[4] = {0.f, 0.f, 0.f, 0.f}, adb[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (p.addend) {                        // uniform
-                        u32x4 qd = {0u, 0u, 0u, 0u};
-                        if (m_ok[mt]) qd = *(const u32x4*)((const T*)p.addend + orow[mt] * p.ldc + p.coff + nb8);
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const auto sw = __builtin_amdgcn_permlane16_swap(qd[h], qd[2 + h], false, false);
-                            const t2 a2 = __builtin_bit_cast(t2, (unsigned)sw[0]), b2 = __builtin_bit_cast(t2, (unsigned)sw[1]);
-                            ada[2 * h] = (float)a2[0]; ada[2 * h + 1] = (float)a2[1];
-                            adb[2 * h] = (float)b2[0]; adb[2 * h + 1] = (float)b2[1];
-                        }
-                    }
-                    unsigned qa[2], qb[2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const t2 a2 = {(T)(act_apply_t<T>(acc[2 * pr][mt][2 * h], act) + ada[2 * h]), (T)(act_apply_t<T>(acc[2 * pr][mt][2 * h + 1], act) + ada[2 * h + 1])};
-                        const t2 b2 = {(T)(act_apply_t<T>(acc[2 * pr + 1][mt][2 * h], act) + adb[2 * h]), (T)(act_apply_t<T>(acc[2 * pr + 1][mt][2 * h + 1], act) + adb[2 * h + 1])};
-                        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a2), __builtin_bit_cast(unsigned, b2), false, false);
-                        qa[h] = sw[0];                     // even rows: own a      | odd rows: partner's b
-                        qb[h] = sw[1];                     // even rows: partner's a | odd rows: own b
-                    }
-                    if (!m_ok[mt]) continue;
-                    T* o = (T*)p.out + orow[mt] * p.ldc + p.coff + nb8;
-                    *(u32x4*)o = (u32x4){qa[0], qa[1], qb[0], qb[1]};
-                }
-            }
-            return;
-        }
-    }
-    if (p.addend) {                                        // narrow paths: the addend at the accumulator positions
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            if (!m_ok[mt]) continue;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int nb4 = n0 + wn * (BN / 2) + nt * 16 + fg * 4;
-                const T* a = (const T*)p.addend + orow[mt] * p.ldc + p.coff + nb4;
-                if (vec_ok && nb4 + 3 < p.N) {
-                    if constexpr (sizeof(T) == 4) {
-                        const f32x4 q = *(const f32x4*)a;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[nt][mt][r] = act_apply_t<T>(acc[nt][mt][r], act) + q[r];
-                    } else {
-                        const typename V16<T>::x4 q = *(const typename V16<T>::x4*)a;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[nt][mt][r] = act_apply_t<T>(acc[nt][mt][r], act) + (float)q[r];
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[nt][mt][r] = act_apply_t<T>(acc[nt][mt][r], act) + (nb4 + r < p.N ? Elem<T>::ld(a + r) : 0.f);
-                }
-            }
-        }
-        act = DM_ACT_NONE;
-    }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        if (!m_ok[mt]) continue;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int nb4 = n0 + wn * (BN / 2) + nt * 16 + fg * 4;
-            if (nb4 >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = act_apply_t<T>(acc[nt][mt][r], act);
-            if (p.out_nchw) {
-                float* o = (float*)p.out;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (nb4 + r < p.N) o[(((size_t)ob[mt] * p.N + nb4 + r) * p.Ho + oy[mt]) * p.Wo + ox[mt]] = v[r];
-            } else {
-                T* o = (T*)p.out + orow[mt] * p.ldc + p.coff + nb4;
-                if (vec_ok && nb4 + 3 < p.N) {
-                    if constexpr (sizeof(T) == 4) {
-                        *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
-                    } else {
-                        typedef typename V16<T>::x4 t4;
-                        t4 q = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
-                        *(t4*)o = q;
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (nb4 + r < p.N) Elem<T>::st(o + r, v[r]);
-                }
-            }
-        }
-    }
+    // the activation is dispatched ONCE per workgroup: with a runtime `act` inside the 64 per-value expressions the epilogue carried
+    // ~2100 scalar branches (three per value, each skipping a GELU / sigmoid body) through 160 KB of code
+    if (p.act == DM_ACT_NONE) conv_store<T, BN, DM_ACT_NONE>(p, acc, m_ok, orow, ob, oy, ox, wn, fg, n0);
+    else if (p.act == DM_ACT_GELU) conv_store<T, BN, DM_ACT_GELU>(p, acc, m_ok, orow, ob, oy, ox, wn, fg, n0);
+    else conv_store<T, BN, -1>(p, acc, m_ok, orow, ob, oy, ox, wn, fg, n0);
 }
 
 // =================================================================================================
