@@ -158,6 +158,16 @@ __device__ __forceinline__ void mma_stage(const char* sA, const char* sB, int wm
 }
 
 // epilogue: z = acc*scale + shift ; optional per-block column statistics ; activation ; store
+// sum over the 16 lanes of a DPP row, result in every lane: quad butterflies, then the two mirrors (v_add_f32 with DPP operands —
+// the __shfl_xor form compiled to 128 ds_bpermute_b32 per lane in the statistics epilogue)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+
 // activation with a compile-time selector (ACTC >= 0) or the runtime value (ACTC < 0)
 template <typename T, int ACTC>
 __device__ __forceinline__ float act_c(float x, int act) {
@@ -298,17 +308,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 
     bool m_ok[4];
     size_t orow[4];
     int ob[4], oy[4], ox[4];
+    // output pixel = GEMM row for the stride-1 NHWC layers (most launches): no divisions by the image extents (8 per lane otherwise)
+    const bool ident = p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.Ho == p.Hq && p.Wo == p.Wq && !p.out_nchw;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int m = m0 + wm * 64 + mt * 16 + fr;
         m_ok[mt] = m < p.M;
         const int mm = m_ok[mt] ? m : 0;
-        const int qx = mm % p.Wq, tq = mm / p.Wq;
-        const int qy = tq % p.Hq;
-        ob[mt] = tq / p.Hq;
-        oy[mt] = qy * p.osy + p.ooy;
-        ox[mt] = qx * p.osx + p.oox;
-        orow[mt] = ((size_t)ob[mt] * p.Ho + oy[mt]) * p.Wo + ox[mt];
+        if (ident) {
+            ob[mt] = oy[mt] = ox[mt] = 0;
+            orow[mt] = (size_t)mm;
+        } else {
+            const int qx = mm % p.Wq, tq = mm / p.Wq;
+            const int qy = tq % p.Hq;
+            ob[mt] = tq / p.Hq;
+            oy[mt] = qy * p.osy + p.ooy;
+            ox[mt] = qx * p.osx + p.oox;
+            orow[mt] = ((size_t)ob[mt] * p.Ho + oy[mt]) * p.Wo + ox[mt];
+        }
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -327,8 +344,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
                     if (m_ok[mt]) { const float z = acc[nt][mt][r]; s1 += z; s2 += z * z; }
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                s1 = row16_sum(s1);
+                s2 = row16_sum(s2);
                 if (fr == 0) {
                     const int nl = wn * (BN / 2) + nt * 16 + fg * 4 + r;
                     sred[(wm * 2 + 0) * BN + nl] = s1;
