@@ -297,14 +297,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 
                                               int fg, int mb, int m0, int n0) {
     constexpr int NT = BN / 32;
     float sc[NT][4], sh[NT][4];
+    // the lane's 4 consecutive channels of a block in one 16-byte load when the vectors are aligned and inside N (16 + 16 dword loads
+    // per lane otherwise, and the first thing the epilogue waits for)
+    const bool sv4 = (((uintptr_t)p.scale | (uintptr_t)p.shift) & 15) == 0 && (n0 & 3) == 0;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt) {
+        const int nb4 = n0 + wn * (BN / 2) + nt * 16 + fg * 4;
+        if (sv4 && nb4 + 3 < p.N) {
+            const f32x4 a = p.scale ? *(const f32x4*)(p.scale + nb4) : (f32x4){1.f, 1.f, 1.f, 1.f};
+            const f32x4 b = p.shift ? *(const f32x4*)(p.shift + nb4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + wn * (BN / 2) + nt * 16 + fg * 4 + r;
-            sc[nt][r] = (p.scale && n < p.N) ? p.scale[n] : 1.f;
-            sh[nt][r] = (p.shift && n < p.N) ? p.shift[n] : 0.f;
+            for (int r = 0; r < 4; ++r) { sc[nt][r] = a[r]; sh[nt][r] = b[r]; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nb4 + r;
+                sc[nt][r] = (p.scale && n < p.N) ? p.scale[n] : 1.f;
+                sh[nt][r] = (p.shift && n < p.N) ? p.shift[n] : 0.f;
+            }
         }
+    }
     bool m_ok[4];
     size_t orow[4];
     int ob[4], oy[4], ox[4];
@@ -352,6 +364,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 
                     sred[(wm * 2 + 1) * BN + nl] = s2;
                 }
             }
+    }
+
+    // the activation is dispatched ONCE per workgroup: with a runtime `act` inside the 64 per-value expressions the epilogue carried
+    // ~2100 scalar branches (three per value, each skipping a GELU / sigmoid body) through 160 KB of code
+    if (p.act == DM_ACT_NONE) conv_store<T, BN, DM_ACT_NONE>(p, acc, m_ok, orow, ob, oy, ox, wn, fg, n0);
+    else if (p.act == DM_ACT_GELU) conv_store<T, BN, DM_ACT_GELU>(p, acc, m_ok, orow, ob, oy, ox, wn, fg, n0);
+    else conv_store<T, BN, -1>(p, acc, m_ok, orow, ob, oy, ox, wn, fg, n0);
+
+    if (p.psum) {                                          // after the stores: the barrier's wait for the slowest wave hides behind them
+        const float* sred = (const float*)smem;
         __syncthreads();
         if (tid < BN && n0 + tid < p.N) {
             if (p.stat_slots > 0) {                        // a few slots the consuming kernel folds itself (no finalize launch)
@@ -364,12 +386,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 
             }
         }
     }
-
-    // the activation is dispatched ONCE per workgroup: with a runtime `act` inside the 64 per-value expressions the epilogue carried
-    // ~2100 scalar branches (three per value, each skipping a GELU / sigmoid body) through 160 KB of code
-    if (p.act == DM_ACT_NONE) conv_store<T, BN, DM_ACT_NONE>(p, acc, m_ok, orow, ob, oy, ox, wn, fg, n0);
-    else if (p.act == DM_ACT_GELU) conv_store<T, BN, DM_ACT_GELU>(p, acc, m_ok, orow, ob, oy, ox, wn, fg, n0);
-    else conv_store<T, BN, -1>(p, acc, m_ok, orow, ob, oy, ox, wn, fg, n0);
 }
 
 // =================================================================================================
