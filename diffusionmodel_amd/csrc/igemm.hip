@@ -739,7 +739,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
         const int y = y0 + hy - 1, x = TW == 8 ? hx - img * 10 - 1 : x0 + hx - 1;
         const bool ok = (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi && img < 4 && hx < TW + 2 + (TW == 8 ? 30 : 0);
         const int pix = ((b + img) * p.Hi + y) * p.Wi + x;
-        const int pix2 = (((b + img) % p.B2) * p.Hi + y) * p.Wi + x;          // CFG sampler: the skip tensor of n samples feeds 2n
+        const int b2 = p.B2 >= p.B ? b + img : (b + img) % p.B2;             // CFG sampler: the skip tensor of n samples feeds 2n (no division otherwise)
+        const int pix2 = (b2 * p.Hi + y) * p.Wi + x;
         hv1[i] = ok && slotb < p.C1 * 2 ? (unsigned)(pix * p.C1 * 2 + slotb) : OOB;
         hv2[i] = ok ? (unsigned)(pix2 * p.C2 * 2 + slotb) : OOB;
     }
