@@ -37,356 +37,9 @@
 // the 8 XCDs, so tile = (bid % 8) * (ntiles / 8) + bid / 8 (bijective form) gives every XCD a contiguous
 // run of tiles — vertically adjacent image rows (shared 3x3 halo) and the n-tiles of one pixel block
 // then meet in the same 4 MiB L2.  Placement only affects speed, never results.
-#include <type_traits>
-#include "common.h"
+#include "igemm_dev.h"
 
-namespace {
-
-constexpr int BM = 128;
-constexpr int ROWB = 128;  // bytes per LDS row per k-step (8 x 16-B vectors)
-
-struct ConvP {
-    const char* in1; const char* in2; const char* w;
-    const float* scale; const float* shift;
-    char* out; float* psum; float* psq;
-    int act, out_nchw;
-    int B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0;
-    int Ho, Wo, osy, osx, ooy, oox, N, ldw, ldc, coff, M;
-    // split-K (LDS-DMA kernels): `splits` workgroups share an output tile, each takes `kper` k-steps (gather kernel) or
-    // channel chunks (halo kernel) and leaves its accumulators in ws; splitk_epilogue_kernel adds them up and finishes
-    int splits, kper;
-    float* ws;
-    int* counters;                               // halo kernels: arrival counter per output tile (the last split to arrive finishes the tile)
-    // four-tap kernel, S2 = false: `npar` (1 or 4) output-parity classes in ONE launch — class q takes workgroups [q, q + 1) * grid / npar,
-    // its own transposed weight pack, tap offsets and output offsets (the four input-gradient launches of a 4x4 / stride-2 layer)
-    int npar;
-    const char* w4[4];
-    int oy4[4], ox4[4], ooy4[4], oox4[4];
-    int B2;                                      // batch of the second source (in2 is read at sample b % B2); == B unless broadcast
-    int stat_slots;                              // 0: psum / psq are [tiles][N] partial rows; S > 0: [S][N] accumulators, tile mb adds into slot mb % S
-    const char* addend;                          // optional tensor of the output's layout / dtype added after the activation (gradient of a forked tensor)
-};
-
-// raw accumulators of one 128 x BN tile as they sit in the registers: [tile][wave][nt][mt][lane] float4 (1 KiB per store)
-template <int BN>
-__device__ __forceinline__ void store_partial(const ConvP& p, const f32x4 (&acc)[BN / 32][4], int split, int tiles, int tile, int wave, int lane) {
-    constexpr int NT = BN / 32;
-    f32x4* dst = (f32x4*)p.ws + ((((size_t)split * tiles + tile) * 4 + wave) * (NT * 4)) * 64 + lane;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) dst[(nt * 4 + mt) * 64] = acc[nt][mt];
-}
-
-// Split-K without a second launch (halo kernels): every split parks its raw accumulators in ws (store_partial), publishes them
-// (release fence) and counts itself in; the split that arrives LAST (no spinning: whoever it is) adds the others' partials to
-// the accumulators it still holds in registers and runs the ordinary epilogue.  Returns false for the splits that are done.
-__device__ __forceinline__ bool splitk_last_arriver(const ConvP& p, f32x4 (&acc)[4][4], char* smem, int split, int ntiles2, int tile_id,
-                                                    int half_tile, int wave4, int tid, int lane) {
-    store_partial<128>(p, acc, split, ntiles2, half_tile, wave4, lane);
-    __threadfence();                                   // the partials are visible device-wide before the count says so
-    __syncthreads();
-    int* flag = (int*)(smem + 16384);
-    if (tid == 0) {
-        const int old = atomicAdd(p.counters + tile_id, 1);
-        const int last = old == p.splits - 1;
-        if (last) p.counters[tile_id] = 0;             // everyone has arrived: ready for the next launch on this stream
-        *flag = last;
-    }
-    __syncthreads();
-    if (!*flag) return false;
-    __threadfence();                                   // acquire: the other splits' partials (written on other XCDs) are read from memory
-    for (int k = 0; k < p.splits; ++k) {
-        if (k == split) continue;
-        const f32x4* src = (const f32x4*)p.ws + ((((size_t)k * ntiles2 + half_tile) * 4 + wave4) * 16) * 64 + lane;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const f32x4 v = __builtin_nontemporal_load(src + (nt * 4 + mt) * 64);
-                acc[nt][mt] += v;
-            }
-    }
-    __syncthreads();                                   // the flag word is LDS the epilogue reuses
-    return true;
-}
-
-__device__ __attribute__((aligned(128))) unsigned int g_zero_page[64];  // source of every padded 16-B vector (v2)
-
-__device__ inline int lds_off(int row, int vec) { return row * ROWB + ((vec ^ (row & 7)) << 4); }
-
-__device__ inline int remap_xcd(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-}
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16> {
-    __device__ static inline void run(const u32x4& a, const u32x4& b, f32x4& c) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    }
-};
-template <> struct Mma<f16> {
-    __device__ static inline void run(const u32x4& a, const u32x4& b, f32x4& c) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    }
-};
-template <> struct Mma<float> {
-    __device__ static inline void run(const u32x4& a, const u32x4& b, f32x4& c) {
-        const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb[j], c, 0, 0, 0);
-    }
-};
-
-// one k-step (two MFMA sub-steps) of a wave's 64 x (BN/2) sub-tile out of the stage at sA / sB
-template <typename T, int BN>
-__device__ __forceinline__ void mma_stage(const char* sA, const char* sB, int wm, int wn, int fr, int fg, f32x4 (&acc)[BN / 32][4]) {
-    constexpr int NT = BN / 32;
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-        u32x4 fb[4], fa[NT];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) fb[mt] = *(const u32x4*)(sA + lds_off(wm * 64 + mt * 16 + fr, sub * 4 + fg));
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) fa[nt] = *(const u32x4*)(sB + lds_off(wn * (BN / 2) + nt * 16 + fr, sub * 4 + fg));
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) Mma<T>::run(fa[nt], fb[mt], acc[nt][mt]);
-    }
-}
-
-// epilogue: z = acc*scale + shift ; optional per-block column statistics ; activation ; store
-// sum over the 16 lanes of a DPP row, result in every lane: quad butterflies, then the two mirrors (v_add_f32 with DPP operands —
-// the __shfl_xor form compiled to 128 ds_bpermute_b32 per lane in the statistics epilogue)
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
-    return v;
-}
-
-// activation with a compile-time selector (ACTC >= 0) or the runtime value (ACTC < 0)
-template <typename T, int ACTC>
-__device__ __forceinline__ float act_c(float x, int act) {
-    if constexpr (ACTC == DM_ACT_NONE) return x;
-    else if constexpr (ACTC >= 0) return act_apply_t<T>(x, ACTC);
-    else return act_apply_t<T>(x, act);
-}
-
-// second half of the epilogue: activation, addend, stores
-template <typename T, int BN, int ACTC>
-__device__ __forceinline__ void conv_store(const ConvP& p, f32x4 (&acc)[BN / 32][4], const bool (&m_ok)[4], const size_t (&orow)[4], const int (&ob)[4],
-                                           const int (&oy)[4], const int (&ox)[4], int wn, int fg, int n0) {
-    constexpr int NT = BN / 32;
-    const bool vec_ok = ((p.ldc | p.coff) & 3) == 0 && !p.out_nchw;
-    const int act = ACTC >= 0 ? ACTC : p.act;
-    bool applied = false;
-    // out = act(z) + addend: the other consumer's gradient of a tensor used twice (ops.GradFork)
-    if constexpr (sizeof(T) == 2 && NT % 2 == 0) {
-        // 16-bit NHWC, both 16-channel blocks of a pair inside N and 16-byte aligned: a lane holds 4 channels (8 B) of blocks a and b;
-        // one v_permlane16_swap per dword trades block b of the even 16-lane rows for block a of the odd rows, so that every lane
-        // ends up with 8 consecutive channels of ONE block -> one 16-byte store per pair instead of two 8-byte ones (half the store
-        // instructions, 64-byte instead of 32-byte segments per pixel).  The addend is fetched the same way — one 16-byte load at the
-        // lane's store address — and taken back to the accumulator layout by the same swap (it is its own inverse), so the sum is
-        // formed in fp32 and rounded once (8-byte loads at the accumulator positions cost +39 us on the 64x64 1x1 input gradient).
-        const bool wide = vec_ok && ((p.ldc | p.coff) & 7) == 0 && n0 + wn * (BN / 2) + NT * 16 <= p.N && ((uintptr_t)p.out & 15) == 0 &&
-                          ((uintptr_t)p.addend & 15) == 0;
-        if (wide) {                                        // workgroup-uniform
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-                for (int pr = 0; pr < NT / 2; ++pr) {
-                    typedef typename V16<T>::x2 t2;
-                    const int blk = 2 * pr + (fg & 1);     // even 16-lane rows store block a, odd rows block b
-                    const int nb8 = n0 + wn * (BN / 2) + blk * 16 + (fg >> 1) * 8;
-                    float ada[4] = {0.f, 0.f, 0.f, 0.f}, adb[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (p.addend) {                        // uniform
-                        u32x4 qd = {0u, 0u, 0u, 0u};
-                        if (m_ok[mt]) qd = *(const u32x4*)((const T*)p.addend + orow[mt] * p.ldc + p.coff + nb8);
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const auto sw = __builtin_amdgcn_permlane16_swap(qd[h], qd[2 + h], false, false);
-                            const t2 a2 = __builtin_bit_cast(t2, (unsigned)sw[0]), b2 = __builtin_bit_cast(t2, (unsigned)sw[1]);
-                            ada[2 * h] = (float)a2[0]; ada[2 * h + 1] = (float)a2[1];
-                            adb[2 * h] = (float)b2[0]; adb[2 * h + 1] = (float)b2[1];
-                        }
-                    }
-                    unsigned qa[2], qb[2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const t2 a2 = {(T)(act_c<T, ACTC>(acc[2 * pr][mt][2 * h], act) + ada[2 * h]), (T)(act_c<T, ACTC>(acc[2 * pr][mt][2 * h + 1], act) + ada[2 * h + 1])};
-                        const t2 b2 = {(T)(act_c<T, ACTC>(acc[2 * pr + 1][mt][2 * h], act) + adb[2 * h]), (T)(act_c<T, ACTC>(acc[2 * pr + 1][mt][2 * h + 1], act) + adb[2 * h + 1])};
-                        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a2), __builtin_bit_cast(unsigned, b2), false, false);
-                        qa[h] = sw[0];                     // even rows: own a      | odd rows: partner's b
-                        qb[h] = sw[1];                     // even rows: partner's a | odd rows: own b
-                    }
-                    if (!m_ok[mt]) continue;
-                    T* o = (T*)p.out + orow[mt] * p.ldc + p.coff + nb8;
-                    *(u32x4*)o = (u32x4){qa[0], qa[1], qb[0], qb[1]};
-                }
-            }
-            return;
-        }
-    }
-    if (p.addend) {                                        // narrow paths: the addend at the accumulator positions
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            if (!m_ok[mt]) continue;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int nb4 = n0 + wn * (BN / 2) + nt * 16 + fg * 4;
-                const T* a = (const T*)p.addend + orow[mt] * p.ldc + p.coff + nb4;
-                if (vec_ok && nb4 + 3 < p.N) {
-                    if constexpr (sizeof(T) == 4) {
-                        const f32x4 q = *(const f32x4*)a;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[nt][mt][r] = act_c<T, ACTC>(acc[nt][mt][r], act) + q[r];
-                    } else {
-                        const typename V16<T>::x4 q = *(const typename V16<T>::x4*)a;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[nt][mt][r] = act_c<T, ACTC>(acc[nt][mt][r], act) + (float)q[r];
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[nt][mt][r] = act_c<T, ACTC>(acc[nt][mt][r], act) + (nb4 + r < p.N ? Elem<T>::ld(a + r) : 0.f);
-                }
-            }
-        }
-        applied = true;                                    // the activation went in before the addend
-    }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        if (!m_ok[mt]) continue;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int nb4 = n0 + wn * (BN / 2) + nt * 16 + fg * 4;
-            if (nb4 >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = applied ? acc[nt][mt][r] : act_c<T, ACTC>(acc[nt][mt][r], act);
-            if (p.out_nchw) {
-                float* o = (float*)p.out;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (nb4 + r < p.N) o[(((size_t)ob[mt] * p.N + nb4 + r) * p.Ho + oy[mt]) * p.Wo + ox[mt]] = v[r];
-            } else {
-                T* o = (T*)p.out + orow[mt] * p.ldc + p.coff + nb4;
-                if (vec_ok && nb4 + 3 < p.N) {
-                    if constexpr (sizeof(T) == 4) {
-                        *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
-                    } else {
-                        typedef typename V16<T>::x4 t4;
-                        t4 q = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
-                        *(t4*)o = q;
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (nb4 + r < p.N) Elem<T>::st(o + r, v[r]);
-                }
-            }
-        }
-    }
-}
-
-template <typename T, int BN>
-__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 32][4], char* smem, int tid, int wm, int wn, int fr,
-                                              int fg, int mb, int m0, int n0) {
-    constexpr int NT = BN / 32;
-    float sc[NT][4], sh[NT][4];
-    // the lane's 4 consecutive channels of a block in one 16-byte load when the vectors are aligned and inside N (16 + 16 dword loads
-    // per lane otherwise, and the first thing the epilogue waits for)
-    const bool sv4 = (((uintptr_t)p.scale | (uintptr_t)p.shift) & 15) == 0 && (n0 & 3) == 0;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int nb4 = n0 + wn * (BN / 2) + nt * 16 + fg * 4;
-        if (sv4 && nb4 + 3 < p.N) {
-            const f32x4 a = p.scale ? *(const f32x4*)(p.scale + nb4) : (f32x4){1.f, 1.f, 1.f, 1.f};
-            const f32x4 b = p.shift ? *(const f32x4*)(p.shift + nb4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { sc[nt][r] = a[r]; sh[nt][r] = b[r]; }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = nb4 + r;
-                sc[nt][r] = (p.scale && n < p.N) ? p.scale[n] : 1.f;
-                sh[nt][r] = (p.shift && n < p.N) ? p.shift[n] : 0.f;
-            }
-        }
-    }
-    bool m_ok[4];
-    size_t orow[4];
-    int ob[4], oy[4], ox[4];
-    // output pixel = GEMM row for the stride-1 NHWC layers (most launches): no divisions by the image extents (8 per lane otherwise)
-    const bool ident = p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.Ho == p.Hq && p.Wo == p.Wq && !p.out_nchw;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + fr;
-        m_ok[mt] = m < p.M;
-        const int mm = m_ok[mt] ? m : 0;
-        if (ident) {
-            ob[mt] = oy[mt] = ox[mt] = 0;
-            orow[mt] = (size_t)mm;
-        } else {
-            const int qx = mm % p.Wq, tq = mm / p.Wq;
-            const int qy = tq % p.Hq;
-            ob[mt] = tq / p.Hq;
-            oy[mt] = qy * p.osy + p.ooy;
-            ox[mt] = qx * p.osx + p.oox;
-            orow[mt] = ((size_t)ob[mt] * p.Ho + oy[mt]) * p.Wo + ox[mt];
-        }
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[nt][mt][r] = acc[nt][mt][r] * sc[nt][r] + sh[nt][r];
-
-    if (p.psum) {
-        float* sred = (float*)smem;  // [2 (wm)][2 (sum,sq)][BN]
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    if (m_ok[mt]) { const float z = acc[nt][mt][r]; s1 += z; s2 += z * z; }
-                s1 = row16_sum(s1);
-                s2 = row16_sum(s2);
-                if (fr == 0) {
-                    const int nl = wn * (BN / 2) + nt * 16 + fg * 4 + r;
-                    sred[(wm * 2 + 0) * BN + nl] = s1;
-                    sred[(wm * 2 + 1) * BN + nl] = s2;
-                }
-            }
-    }
-
-    // the activation is dispatched ONCE per workgroup: with a runtime `act` inside the 64 per-value expressions the epilogue carried
-    // ~2100 scalar branches (three per value, each skipping a GELU / sigmoid body) through 160 KB of code
-    if (p.act == DM_ACT_NONE) conv_store<T, BN, DM_ACT_NONE>(p, acc, m_ok, orow, ob, oy, ox, wn, fg, n0);
-    else if (p.act == DM_ACT_GELU) conv_store<T, BN, DM_ACT_GELU>(p, acc, m_ok, orow, ob, oy, ox, wn, fg, n0);
-    else conv_store<T, BN, -1>(p, acc, m_ok, orow, ob, oy, ox, wn, fg, n0);
-
-    if (p.psum) {                                          // after the stores: the barrier's wait for the slowest wave hides behind them
-        const float* sred = (const float*)smem;
-        __syncthreads();
-        if (tid < BN && n0 + tid < p.N) {
-            if (p.stat_slots > 0) {                        // a few slots the consuming kernel folds itself (no finalize launch)
-                // fp64 accumulators: precision of the old fp64 fold over the partial rows, and the arrival order moves nothing visible
-                atomicAdd((double*)p.psum + (size_t)(mb % p.stat_slots) * p.N + n0 + tid, (double)(sred[0 * BN + tid] + sred[2 * BN + tid]));
-                atomicAdd((double*)p.psq + (size_t)(mb % p.stat_slots) * p.N + n0 + tid, (double)(sred[1 * BN + tid] + sred[3 * BN + tid]));
-            } else {
-                p.psum[(size_t)mb * p.N + n0 + tid] = sred[0 * BN + tid] + sred[2 * BN + tid];
-                p.psq[(size_t)mb * p.N + n0 + tid] = sred[1 * BN + tid] + sred[3 * BN + tid];
-            }
-        }
-    }
-}
+namespace dmk {
 
 // =================================================================================================
 // v1: register staging
@@ -506,7 +159,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 typedef __attribute__((address_space(3))) void* lds_vptr;
 typedef const __attribute__((address_space(1))) void* gbl_vptr;
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename T, int BN, int NS>
 __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvP p) {
@@ -663,201 +315,6 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvP p) {
 }
 
 // =================================================================================================
-// v5: halo-resident 3x3 stride-1 kernel (bf16)
-// =================================================================================================
-// The gather kernels above re-fetch every input pixel once per tap: a 128x128 tile pulls 32 KiB from L2
-// into LDS per k-step, and the L2->LDS fill rate of a CU (~70 GB/s, MI355X_MICROARCH.md "Indexed rows:
-// gather into LDS"), not the MFMA, then bounds the 64x64 / 32x32 / 16x16 layers at < 50 % of peak.  Here a
-// 512-thread workgroup owns 256 output pixels = TH full image rows (W == TW in {64, 32, 16}) x 128 output
-// channels and keeps the INPUT HALO of one 64-channel chunk — (TH+2) x (TW+2) pixels x 128 B — resident
-// in LDS: all 9 taps are MFMA'd out of it through shifted fragment addresses, only the weights stream
-// (16 KiB per k-step, 3-stage ring).  L2->LDS bytes per k-step drop from 2 x 32 KiB (two 128x128
-// workgroups) to ~21.6 KiB for the same MFMA work.
-//   * halo image: row hp = hy*HS + hx (HS = TW+8, a multiple of 8), 128 B per row, 16-B slot v stored at
-//     v ^ (hp & 7).  As HS % 8 == 0 a tap shift (ky, kx) changes hp & 7 only through kx: the fragment
-//     addresses are 3 (kx) x 2 (sub-step) x 4 (pixel group) precomputed VGPRs plus an immediate.
-//   * staging: `buffer_load_dwordx4 ... lds` with a per-lane 32-bit offset that never changes (pixel /
-//     weight-row offset, or 0x80000000 = out of range -> the DMA writes zeros: image border, n >= N) and a
-//     scalar offset per k-step (channel chunk / tap).  No per-step address VALU.
-//   * the 9 taps are unrolled: ring stage = tap % 3, the next chunk's halo (<= 54 pieces of 8 px) is
-//     fetched one piece per wave per tap during taps 0..6 into the other halo buffer, all waits are
-//     compile-time `s_waitcnt vmcnt(N)` + one raw s_barrier per k-step.
-//   * 8 waves = 4 (pixel rows of 64) x 2 (64 channels): the wave tile, accumulator layout and epilogue are
-//     those of the 128x128 kernels (each half of the tile emits its own 128-row statistics partial).
-typedef __attribute__((address_space(3))) void* lds_dst;
-
-constexpr int HALO_PIECES = 54;                       // 1-KiB pieces per halo buffer (TW=64: 6x72/8, TW=16: 18x24/8)
-constexpr int HALO_BYTES = HALO_PIECES * 1024;
-constexpr int WSTAGE = 128 * ROWB;                    // one weight stage: 128 rows (n) x 128 B
-constexpr int HALO_LDS = 2 * HALO_BYTES + 3 * WSTAGE; // 159,744 B
-constexpr unsigned OOB = 0x80000000u;
-constexpr int SRD_FLAGS = 0x00020000;
-
-template <typename T, int TW, bool FLIP>
-__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
-    // TW = 8 (8x8 images): the tile is FOUR whole images laid side by side in the halo, each with its own zero columns
-    // ([0 A 0][0 B 0][0 C 0][0 D 0], 10 columns apiece): rows stay multiples of 8 pixels, a wave (64 pixels) is one image
-    constexpr int TH = TW == 8 ? 8 : 256 / TW, HS = TW == 8 ? 40 : TW + 8, HR = TH + 2, NP = HR * HS / 8;
-    static_assert(NP <= HALO_PIECES, "halo does not fit");
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [halo 0][halo 1][w 0][w 1][w 2]
-    char* const sW = smem + 2 * HALO_BYTES;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm4 = wave & 3, wn = wave >> 2;
-    const int fr = lane & 15, fg = lane >> 4;
-    const int nb_n = (p.N + 127) >> 7;
-    const int ntiles = gridDim.x / p.splits;
-    const int split = blockIdx.x / ntiles;
-    const int bid = remap_xcd(blockIdx.x - split * ntiles, ntiles);
-    const int mb = bid / nb_n, nb = bid - mb * nb_n;
-    const int m0 = mb * 256, n0 = nb * 128;
-    const int C = p.C1 + p.C2;
-    const int c_lo = split * p.kper;                       // this split's channel chunks [c_lo, nchunks)
-    const int nchunks = min((C + 63) >> 6, c_lo + p.kper);    // a lone partial chunk (C < 64, single source) reads zeros past C
-    // TW = 64 also serves wider images (Wi a multiple of 64): the tile is then 4 rows x 64 COLUMNS x0 .. x0+63 and its
-    // left / right halo columns are real pixels of the neighbouring tile
-    const int tcols = TW == 64 ? p.Wi >> 6 : 1;
-    const int tiles_img = TW == 8 ? 1 : ((p.Hi * TW) >> 8) * tcols;
-    const int b = TW == 8 ? mb * 4 : mb / tiles_img;
-    const int trem = mb - b * tiles_img;
-    const int y0 = TW == 8 ? 0 : (trem / tcols) * TH, x0 = (trem % tcols) * 64;
-
-    const int pix_img = p.B * p.Hi * p.Wi;
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.N * p.ldw * 2, SRD_FLAGS);
-
-    // ---- per-lane constants (nothing below changes inside the loop) ----
-    const int lrow = lane >> 3;
-    const int slotb = ((lane & 7) ^ lrow) << 4;          // byte offset of the logical vector this lane fetches
-    unsigned hv1[7], hv2[7];                               // halo pieces wave + 8 i: byte offset of the pixel in source 1 / 2
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const int q = min(wave + 8 * i, NP - 1);           // surplus pieces re-fetch the last one (same bytes, same place)
-        const int hp = q * 8 + lrow;
-        const int hy = hp / HS, hx = hp - hy * HS;
-        const int img = TW == 8 ? hx / 10 : 0;                     // TW = 8: image of the tile this halo column belongs to
-        const int y = y0 + hy - 1, x = TW == 8 ? hx - img * 10 - 1 : x0 + hx - 1;
-        const bool ok = (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi && img < 4 && hx < TW + 2 + (TW == 8 ? 30 : 0);
-        const int pix = ((b + img) * p.Hi + y) * p.Wi + x;
-        const int b2 = p.B2 >= p.B ? b + img : (b + img) % p.B2;             // CFG sampler: the skip tensor of n samples feeds 2n (no division otherwise)
-        const int pix2 = (b2 * p.Hi + y) * p.Wi + x;
-        hv1[i] = ok && slotb < p.C1 * 2 ? (unsigned)(pix * p.C1 * 2 + slotb) : OOB;
-        hv2[i] = ok ? (unsigned)(pix2 * p.C2 * 2 + slotb) : OOB;
-    }
-    unsigned wv[2];                                        // weight pieces 2 wave + j: 8 rows (n) x 128 B
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + (wave * 2 + j) * 8 + lrow;
-        wv[j] = n < p.N && slotb < C * 2 ? (unsigned)(n * p.ldw * 2 + slotb) : OOB;
-    }
-    int hoff[3][2][4];                                     // pixel-operand fragment addresses in the current halo buffer
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        int ly, col;                                        // halo row / column of this lane's pixel of the 16-pixel group (tap 0,0)
-        if constexpr (TW == 8) {                            // group = rows 2 mt, 2 mt + 1 of image wm4
-            ly = mt * 2 + (fr >> 3);
-            col = wm4 * 10 + (fr & 7);
-        } else {
-            const int g = wm4 * 4 + mt;
-            ly = g / (TW / 16);
-            col = (g - ly * (TW / 16)) * 16 + fr;
-        }
-        const int base = (ly * HS + col) * ROWB;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) hoff[kx][sub][mt] = base + (((sub * 4 + fg) ^ ((col + kx) & 7)) << 4);
-    }
-    int woff[2][4];                                        // weight-operand fragment addresses within a stage
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) woff[sub][nt] = lds_off(wn * 64 + nt * 16 + fr, sub * 4 + fg);
-
-    auto issue_w = [&](int tap, int chunk, int stage) {    // weights of k-step (chunk, tap) -> ring stage
-        const bool live = chunk < nchunks;
-        const int soff = (tap * C + (chunk << 6)) * 2;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_dst)(sW + stage * WSTAGE + (wave * 2 + j) * 1024), 16, live ? wv[j] : OOB,
-                                                     soff, 0, 0);
-    };
-    auto issue_h = [&](int i, int chunk, int buf) {        // halo piece wave + 8 i of `chunk` -> halo buffer
-        const bool live = chunk < nchunks;
-        const int c0 = chunk << 6;
-        const bool first = c0 < p.C1;
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? p.in1 : p.in2), 0,
-                                                                           first ? pix_img * p.C1 * 2 : p.B2 * p.Hi * p.Wi * p.C2 * 2, SRD_FLAGS);
-        const unsigned v = first ? hv1[i] : hv2[i];
-        const int q = min(wave + 8 * i, NP - 1);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_dst)(smem + buf * HALO_BYTES + q * 1024), 16, live ? v : OOB,
-                                                 (first ? c0 : c0 - p.C1) * 2, 0, 0);
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-    for (int i = 0; i < 7; ++i) issue_h(i, c_lo, 0);
-    issue_w(0, c_lo, 0);
-    issue_w(1, c_lo, 1);
-    int hdelta = HALO_BYTES;
-    {
-        for (int chunk = c_lo; chunk < nchunks; ++chunk) {
-            const int nbuf = (chunk - c_lo + 1) & 1;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                // everything older than the previous step's group (2 weight pieces + its halo piece) has landed
-                if (tap >= 1 && tap <= 7) wait_vmcnt<3>();
-                else wait_vmcnt<2>();
-                __builtin_amdgcn_s_barrier();
-                const int t2 = (tap + 2) % 9;
-                issue_w(t2, chunk + (tap + 2 >= 9 ? 1 : 0), t2 % 3);
-                if (tap < 7) issue_h(tap, chunk + 1, nbuf);
-                const int ky = FLIP ? 2 - tap / 3 : tap / 3, kx = FLIP ? 2 - tap % 3 : tap % 3;   // halo offset of this tap
-                const char* sWs = sW + (tap % 3) * WSTAGE;
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub) {
-                    u32x4 fb[4], fa[4];
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) fb[mt] = *(const u32x4*)(smem + hoff[kx][sub][mt] + (ky * HS + kx) * ROWB);
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) fa[nt] = *(const u32x4*)(sWs + woff[sub][nt]);
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) Mma<T>::run(fa[nt], fb[mt], acc[nt][mt]);
-                }
-            }
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) hoff[kx][sub][mt] += hdelta;
-            hdelta = -hdelta;
-        }
-    }
-    wait_vmcnt<0>();                     // the surplus (out-of-range) pieces of the last steps
-    __syncthreads();                     // the epilogue reuses the LDS for the statistics fold
-    const int half = wm4 >> 1;
-    if (p.splits > 1) {                  // the two 128-row halves are half-tiles 2 mb, 2 mb + 1 of the partial layout
-        if (p.counters == nullptr) {     // two-launch form: splitk_epilogue_kernel folds the partials
-            store_partial<128>(p, acc, split, ntiles * 2, (mb * 2 + half) * nb_n + nb, (wm4 & 1) + 2 * wn, lane);
-            return;
-        }
-        if (!splitk_last_arriver(p, acc, smem, split, ntiles * 2, bid, (mb * 2 + half) * nb_n + nb, (wm4 & 1) + 2 * wn, tid, lane)) return;
-    }
-    const int tidh = (((wave & 1) + 2 * wn) << 6) + lane;
-    // first output pixel of this wave's 64: linear in the tile for whole-row tiles, its own image row for column tiles
-    const int mw = (TW == 64 && tcols > 1) ? ((b * p.Hi + y0 + wm4) * p.Wi + x0) : m0 + wm4 * 64;
-    conv_epilogue<T, 128>(p, acc, smem + half * 4096, tidh, wm4 & 1, wn, fr, fg, mb * 2 + half, mw - (wm4 & 1) * 64, n0);
-}
-
-// =================================================================================================
 // v7: pointwise (1x1) convolution with a short reduction — operands straight from global memory
 // =================================================================================================
 // The 1x1 layers of UnetDown (channel_compress C -> C/4, ch_adjust C/4 -> Cout: new_scripy.py:217-222) and their input gradients reduce
@@ -911,243 +368,6 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvP p) {
     conv_epilogue<T, BN>(p, acc, smem, tid, wm, wn, fr, fg, mb, m0, n0);
 }
 
-// =================================================================================================
-// v6: halo-resident kernel for FOUR-tap layers: the 4x4 stride-2 convolution and its input gradient
-// =================================================================================================
-// A 4x4 / stride 2 / pad 1 convolution (new_scripy.py:229, UnetDown.down[4]) re-reads every input pixel for 4 of its 16 taps; on the
-// gather kernel that is 4x the L2->LDS fill of the 3x3 layers per MFMA and the layers ran at 340-490 TFLOP/s.  Split the input into
-// its four pixel-parity sub-images V_g(y, x) = X(2y + py, 2x + px): with (ky - 1) = 2a + py every tap reads ONE sub-image at offset
-// a in {-1, 0, +1} — py = 0: (ky, a) = (1, 0), (3, +1);  py = 1: (0, -1), (2, 0) — so the layer is a sum over (sub-image, 64-channel
-// chunk) of FOUR-tap contributions out of that sub-image's halo, and the halo can stay resident exactly as in the 3x3 kernel (same
-// tile geometry over the OUTPUT image, same LDS image, same fragment addresses).  The sub-images are never materialised: the halo
-// DMA's per-lane pixel offsets simply step by two pixels, the parity is a scalar offset per chunk.  S2 = true is that forward form
-// (weights straight from the [N][16][C] pack).  S2 = false is the input gradient of one output-parity class: a plain 2x2-tap
-// convolution over dy with tap offsets from (ty, tx, oy0, ox0) and a strided output (osy = osx = 2; the epilogue maps it), weights
-// from the per-class transposed pack [c][4][n].
-//   * 4 k-steps per chunk on a 3-stage weight ring: the stage of a step is (4 * chunk + j) % 3, not a compile-time constant as with
-//     9 taps.  It is a scalar: the DMA destination takes it as such, the fragment reads add it to their 8 addresses (8 VALU per
-//     32 MFMAs; three rotating address sets instead cost 16 more VGPRs and pushed the kernel into scratch).
-//   * the tap offset (dy, dx) of a step is a scalar too: a 9-way switch picks the tap body with the offset as an immediate.
-//   * next chunk's halo (<= 54 pieces, 7 per wave) is fetched 3 + 2 + 2 pieces during steps 0..2; waits are compile-time vmcnt.
-template <typename T, int TW, bool S2>
-__global__ __launch_bounds__(512) void conv_tap4_halo_kernel(const ConvP pp) {
-    constexpr int TH = TW == 8 ? 8 : 256 / TW, HS = TW == 8 ? 40 : TW + 8, HR = TH + 2, NP = HR * HS / 8;
-    static_assert(NP <= HALO_PIECES, "halo does not fit");
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [halo 0][halo 1][w 0][w 1][w 2]
-    char* const sW = smem + 2 * HALO_BYTES;
-
-    // parity class of this workgroup (S2 = false with npar = 4): its weight pack, tap offsets and output offsets replace the descriptor's
-    ConvP p = pp;
-    const int gpar = (int)gridDim.x / pp.npar;             // workgroups per parity class
-    const int par = (int)blockIdx.x / gpar;
-    const int blk = (int)blockIdx.x - par * gpar;
-    if (!S2 && pp.npar > 1) {
-        p.w = pp.w4[par];
-        p.oy0 = pp.oy4[par]; p.ox0 = pp.ox4[par];
-        p.ooy = pp.ooy4[par]; p.oox = pp.oox4[par];
-    }
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm4 = wave & 3, wn = wave >> 2;
-    const int fr = lane & 15, fg = lane >> 4;
-    const int nb_n = (p.N + 127) >> 7;
-    const int ntiles = gpar / p.splits;
-    const int split = blk / ntiles;
-    const int bid = remap_xcd(blk - split * ntiles, ntiles);
-    const int mb = bid / nb_n, nb = bid - mb * nb_n;
-    const int m0 = mb * 256, n0 = nb * 128;
-    const int CK = p.C1;                                   // reduction channels per tap (single source)
-    const int cpg = CK >> 6;                               // 64-channel chunks per sub-image
-    const int nch_total = S2 ? 4 * cpg : cpg;
-    const int c_lo = split * p.kper;
-    const int nchunks = min(nch_total, c_lo + p.kper);
-    const int tiles_img = TW == 8 ? 1 : (p.Hq * TW) >> 8;
-    const int b = TW == 8 ? mb * 4 : mb / tiles_img;
-    const int y0 = TW == 8 ? 0 : (mb - b * tiles_img) * TH;
-
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.N * p.ldw * 2, SRD_FLAGS);
-    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.in1, 0, p.B * p.Hi * p.Wi * CK * 2, SRD_FLAGS);
-
-    const int lrow = lane >> 3;
-    const int slotb = ((lane & 7) ^ lrow) << 4;
-    unsigned hv[7];                                        // halo pieces wave + 8 i: byte offset of the pixel (sub-image 0,0)
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const int q = min(wave + 8 * i, NP - 1);
-        const int hp = q * 8 + lrow;
-        const int hy = hp / HS, hx = hp - hy * HS;
-        const int img = TW == 8 ? hx / 10 : 0;
-        const int y = y0 + hy - 1, x = TW == 8 ? hx - img * 10 - 1 : hx - 1;        // position in the output-sized (sub-)image
-        const bool ok = (unsigned)y < (unsigned)p.Hq && (unsigned)x < (unsigned)p.Wq && img < 4 && hx < TW + 2 + (TW == 8 ? 30 : 0);
-        const int pix = S2 ? ((b + img) * p.Hi + 2 * y) * p.Wi + 2 * x : ((b + img) * p.Hi + y) * p.Wi + x;
-        hv[i] = ok ? (unsigned)(pix * CK * 2 + slotb) : OOB;
-    }
-    unsigned wv[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + (wave * 2 + j) * 8 + lrow;
-        wv[j] = n < p.N ? (unsigned)(n * p.ldw * 2 + slotb) : OOB;
-    }
-    int hoff[3][2][4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        int ly, col;
-        if constexpr (TW == 8) {
-            ly = mt * 2 + (fr >> 3);
-            col = wm4 * 10 + (fr & 7);
-        } else {
-            const int g = wm4 * 4 + mt;
-            ly = g / (TW / 16);
-            col = (g - ly * (TW / 16)) * 16 + fr;
-        }
-        const int base = (ly * HS + col) * ROWB;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) hoff[kx][sub][mt] = base + (((sub * 4 + fg) ^ ((col + kx) & 7)) << 4);
-    }
-    int woff[2][4];                                        // weight fragment addresses within stage 0; the stage offset of a step is a scalar
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) woff[sub][nt] = 2 * HALO_BYTES + lds_off(wn * 64 + nt * 16 + fr, sub * 4 + fg);
-
-    // (dy, dx) in {-1, 0, 1}^2 and the weight-row offset of k-step (chunk, j)
-    auto tap_of = [&](int chunk, int j, int& dy, int& dx, int& soff) {
-        if constexpr (S2) {
-            const int g = chunk / cpg, cc = chunk - g * cpg;
-            const int py = g >> 1, px = g & 1;
-            dy = (j >> 1) - py;
-            dx = (j & 1) - px;
-            const int ky = 2 * dy + py + 1, kx = 2 * dx + px + 1;
-            soff = ((ky * 4 + kx) * CK + (cc << 6)) * 2;
-        } else {
-            dy = (j >> 1) * p.ty + p.oy0;
-            dx = (j & 1) * p.tx + p.ox0;
-            soff = (j * CK + (chunk << 6)) * 2;
-        }
-    };
-    auto issue_w = [&](int chunk, int j, int stage) {
-        const bool live = chunk < nchunks;
-        int dy, dx, soff;
-        tap_of(live ? chunk : c_lo, j, dy, dx, soff);
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_dst)(sW + stage * WSTAGE + (wave * 2 + k) * 1024), 16, live ? wv[k] : OOB, soff, 0, 0);
-    };
-    auto issue_h = [&](int i, int chunk, int buf) {
-        const bool live = chunk < nchunks;
-        int soff;
-        if constexpr (S2) {
-            const int ch = live ? chunk : c_lo;
-            const int g = ch / cpg, cc = ch - g * cpg;
-            soff = (((g >> 1) * p.Wi + (g & 1)) * CK + (cc << 6)) * 2;
-        } else {
-            soff = (chunk << 6) * 2;
-        }
-        const int q = min(wave + 8 * i, NP - 1);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_dst)(smem + buf * HALO_BYTES + q * 1024), 16, live ? hv[i] : OOB, soff, 0, 0);
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-    for (int i = 0; i < 7; ++i) issue_h(i, c_lo, 0);
-    issue_w(c_lo, 0, 0);
-    issue_w(c_lo, 1, 1);
-    int hdelta = HALO_BYTES;
-    int s0 = 0;                                            // ring stage of step 0 of the current chunk
-    for (int chunk = c_lo; chunk < nchunks; ++chunk) {
-        const int nbuf = (chunk - c_lo + 1) & 1;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // everything older than the previous step's group has landed (groups: step 0 = 2 w + 3 h, steps 1, 2 = 2 w + 2 h, step 3 = 2 w)
-            if (j == 0) wait_vmcnt<2>();
-            else if (j == 1) wait_vmcnt<5>();
-            else wait_vmcnt<4>();
-            __builtin_amdgcn_s_barrier();
-            {
-                const int j2 = (j + 2) & 3;
-                int st = s0 + j + 2;
-                st -= st >= 3 ? 3 : 0;
-                st -= st >= 3 ? 3 : 0;
-                issue_w(chunk + (j + 2 >= 4 ? 1 : 0), j2, st);
-            }
-            if (j == 0) { issue_h(0, chunk + 1, nbuf); issue_h(1, chunk + 1, nbuf); issue_h(2, chunk + 1, nbuf); }
-            else if (j == 1) { issue_h(3, chunk + 1, nbuf); issue_h(4, chunk + 1, nbuf); }
-            else if (j == 2) { issue_h(5, chunk + 1, nbuf); issue_h(6, chunk + 1, nbuf); }
-            int dy, dx, soff_unused;
-            tap_of(chunk, j, dy, dx, soff_unused);
-            const int code = (dy + 1) * 3 + (dx + 1);
-            int wst = s0 + j;                                  // ring stage of this step (scalar)
-            wst -= wst >= 3 ? 3 : 0;
-            wst -= wst >= 3 ? 3 : 0;
-            wst *= WSTAGE;
-            auto body = [&](auto KY, auto KX) {
-                constexpr int ky = decltype(KY)::value, kx = decltype(KX)::value;
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub) {
-                    u32x4 fb[4], fa[4];
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) fb[mt] = *(const u32x4*)(smem + hoff[kx][sub][mt] + (ky * HS + kx) * ROWB);
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) fa[nt] = *(const u32x4*)(smem + woff[sub][nt] + wst);
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) Mma<T>::run(fa[nt], fb[mt], acc[nt][mt]);
-                }
-            };
-            using I0 = std::integral_constant<int, 0>;
-            using I1 = std::integral_constant<int, 1>;
-            using I2 = std::integral_constant<int, 2>;
-            switch (code) {
-                case 0: body(I0{}, I0{}); break;
-                case 1: body(I0{}, I1{}); break;
-                case 2: body(I0{}, I2{}); break;
-                case 3: body(I1{}, I0{}); break;
-                case 4: body(I1{}, I1{}); break;
-                case 5: body(I1{}, I2{}); break;
-                case 6: body(I2{}, I0{}); break;
-                case 7: body(I2{}, I1{}); break;
-                default: body(I2{}, I2{}); break;
-            }
-        }
-        // 4 steps = one turn of the 3-stage ring plus one
-        s0 = s0 == 2 ? 0 : s0 + 1;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) hoff[kx][sub][mt] += hdelta;
-        hdelta = -hdelta;
-    }
-    wait_vmcnt<0>();
-    __syncthreads();
-    const int half = wm4 >> 1;
-    if (p.splits > 1) {                  // the two 128-row halves are half-tiles 2 mb, 2 mb + 1 of the partial layout
-        // (never with npar > 1: the launcher takes all four classes in one launch only when that fills the chip without a split)
-        if (p.counters == nullptr) {     // two-launch form: splitk_epilogue_kernel folds the partials
-            store_partial<128>(p, acc, split, ntiles * 2, (mb * 2 + half) * nb_n + nb, (wm4 & 1) + 2 * wn, lane);
-            return;
-        }
-        if (!splitk_last_arriver(p, acc, smem, split, ntiles * 2, bid, (mb * 2 + half) * nb_n + nb, (wm4 & 1) + 2 * wn, tid, lane)) return;
-    }
-    const int tidh = (((wave & 1) + 2 * wn) << 6) + lane;
-    conv_epilogue<T, 128>(p, acc, smem + half * 4096, tidh, wm4 & 1, wn, fr, fg, mb * 2 + half, m0 + wm4 * 64 - (wm4 & 1) * 64, n0);
-}
-
-// halo kernels with split channel chunks: 0 (default) = separate splitk_epilogue_kernel launch, 1 = the last split to arrive finishes the
-// tile in the same launch.  The in-kernel form is bit-exact and 2.0 ms per train step SLOWER (17.6 vs 15.5 ms, same box, r02): the
-// agent-scope release / acquire fences it needs write back and invalidate the XCD's whole L2 (the eight L2s are not coherent with
-// each other), once per workgroup — far more than the 34 epilogue launches of ~13 us it removes.  The same holds for an in-kernel
-// reduction of the weight-gradient splits; cross-workgroup hand-offs stay on kernel boundaries.
 int g_splitk_inkernel = 0;
 int g_last_path = 0;  // kernel family the last dm_conv launch used: 0 = gather (conv_igemm*), 1 = conv3x3_halo_kernel
 
@@ -1179,38 +399,6 @@ int launch_bn(const ConvP& p, int64_t grid, int variant, hipStream_t st) {
     return rc;
 }
 
-template <typename T, int TW, bool FLIP>
-int launch_halo(const ConvP& p, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, TW, FLIP>, hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
-        if (e != hipSuccess) { dm_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", HALO_LDS, hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
-    }
-    const int tiles = (p.M / 256) * cdiv(p.N, 128);
-    ConvP q = p;
-    // few tiles, deep K (the 8x8 / 16x16 layers): split the channel chunks over workgroups until the chip is full
-    const int nchunks = (p.C1 + p.C2 + 63) / 64;
-    if (tiles <= 128 && nchunks >= 4 && dm_g_ws != nullptr && p.Wi <= 64) {     // (the split epilogue assumes whole-row tiles)
-        int splits = 256 / tiles;
-        if (splits > nchunks / 2) splits = nchunks / 2;
-        if (splits >= 2 && (int64_t)splits * tiles * 2 * (128 * 128 * 4) <= dm_g_ws_bytes) {
-            q.kper = cdiv(nchunks, splits);
-            q.splits = cdiv(nchunks, q.kper);
-            q.ws = dm_g_ws;
-            q.counters = g_splitk_inkernel ? dm_g_counters : nullptr;   // the last split to arrive runs the epilogue in the same launch
-        }
-    }
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TW, FLIP>), dim3((unsigned)(tiles * q.splits)), dim3(512), HALO_LDS, st, q);
-    DM_LAUNCH_CHECK();
-    g_last_path = 1;
-    if (q.splits > 1 && q.counters == nullptr) {
-        hipLaunchKernelGGL((splitk_epilogue_kernel<T, 128>), dim3((unsigned)(tiles * 2)), dim3(256), 0, st, q);
-        DM_LAUNCH_CHECK();
-    }
-    return DM_OK;
-}
-
 // 3x3, stride 1, pad 1, whole image rows of 16/32/64 pixels, 64-channel chunks, byte offsets below 2^31
 bool halo_eligible(const ConvP& p) {
     if (p.T != 9 || p.KW != 3 || p.sy != 1 || p.sx != 1) return false;
@@ -1232,37 +420,6 @@ bool halo_eligible(const ConvP& p) {
     return pix * cmax * 2 < (1ll << 31) && (int64_t)p.N * p.ldw * 2 < (1ll << 31);
 }
 
-template <typename T, int TW, bool S2>
-int launch_tap4(const ConvP& p, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_tap4_halo_kernel<T, TW, S2>, hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
-        if (e != hipSuccess) { dm_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", HALO_LDS, hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
-    }
-    const int tiles = (p.M / 256) * cdiv(p.N, 128) * p.npar;
-    ConvP q = p;
-    const int nchunks = (S2 ? 4 : 1) * (p.C1 / 64);
-    if (p.npar == 1 && tiles <= 128 && nchunks >= 4 && dm_g_ws != nullptr) {       // few tiles, deep K: split the chunks over workgroups
-        int splits = 256 / tiles;
-        if (splits > nchunks / 2) splits = nchunks / 2;
-        if (splits >= 2 && (int64_t)splits * tiles * 2 * (128 * 128 * 4) <= dm_g_ws_bytes) {
-            q.kper = cdiv(nchunks, splits);
-            q.splits = cdiv(nchunks, q.kper);
-            q.ws = dm_g_ws;
-            q.counters = g_splitk_inkernel ? dm_g_counters : nullptr;
-        }
-    }
-    hipLaunchKernelGGL((conv_tap4_halo_kernel<T, TW, S2>), dim3((unsigned)(tiles * q.splits)), dim3(512), HALO_LDS, st, q);
-    DM_LAUNCH_CHECK();
-    g_last_path = 2;
-    if (q.splits > 1 && q.counters == nullptr) {
-        hipLaunchKernelGGL((splitk_epilogue_kernel<T, 128>), dim3((unsigned)(tiles * 2)), dim3(256), 0, st, q);
-        DM_LAUNCH_CHECK();
-    }
-    return DM_OK;
-}
-
 // 0: not eligible; 1: the 4x4 / stride-2 / pad-1 forward form (S2); 2: a 2x2-tap stride-1 gather with offsets in {-1, 0, 1}
 // (the input gradient of one output-parity class of that layer).  Output image rows of 8 (four images per tile), 16, 32 or 64 pixels.
 int g_tap4 = 1;
@@ -1281,14 +438,6 @@ int tap4_mode(const ConvP& p) {
         return 2;
     }
     return 0;
-}
-
-template <typename T, bool S2>
-int launch_tap4_tw(const ConvP& p, hipStream_t st) {
-    if (p.Wq == 64) return launch_tap4<T, 64, S2>(p, st);
-    if (p.Wq == 32) return launch_tap4<T, 32, S2>(p, st);
-    if (p.Wq == 16) return launch_tap4<T, 16, S2>(p, st);
-    return launch_tap4<T, 8, S2>(p, st);
 }
 
 int g_pw = 1;
@@ -1322,16 +471,10 @@ int launch_conv(const ConvP& p, bool small_offsets, hipStream_t st) {
         }
         if (g_variant == 5 && small_offsets) {
             const int m4 = tap4_mode(p);
-            if (m4 == 1) return launch_tap4_tw<T, true>(p, st);
-            if (m4 == 2) return launch_tap4_tw<T, false>(p, st);
+            if (m4 == 1) return launch_tap4_any(p, std::is_same<T, f16>::value, true, st);
+            if (m4 == 2) return launch_tap4_any(p, std::is_same<T, f16>::value, false, st);
         }
-        if (g_variant == 5 && halo_eligible(p)) {
-            const bool flip = p.ty < 0;
-            if (p.Wi >= 64) return flip ? launch_halo<T, 64, true>(p, st) : launch_halo<T, 64, false>(p, st);
-            if (p.Wi == 32) return flip ? launch_halo<T, 32, true>(p, st) : launch_halo<T, 32, false>(p, st);
-            if (p.Wi == 16) return flip ? launch_halo<T, 16, true>(p, st) : launch_halo<T, 16, false>(p, st);
-            return flip ? launch_halo<T, 8, true>(p, st) : launch_halo<T, 8, false>(p, st);
-        }
+        if (g_variant == 5 && halo_eligible(p)) return launch_halo_any(p, std::is_same<T, f16>::value, st);
     }
     const int mblocks = cdiv(p.M, BM);
     int bn = 128;
@@ -1372,7 +515,15 @@ int launch_conv(const ConvP& p, bool small_offsets, hipStream_t st) {
     return DM_OK;
 }
 
-}  // namespace
+int launch_splitk_epilogue128(const ConvP& q, bool is_f16, unsigned grid, hipStream_t st) {
+    if (is_f16) hipLaunchKernelGGL((splitk_epilogue_kernel<f16, 128>), dim3(grid), dim3(256), 0, st, q);
+    else hipLaunchKernelGGL((splitk_epilogue_kernel<bf16, 128>), dim3(grid), dim3(256), 0, st, q);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+}  // namespace dmk
+using namespace dmk;
 
 extern "C" int dm_set_conv_tap4(int on) { g_tap4 = (on & 1) != 0; g_pw = (on & 2) == 0; return DM_OK; }   // bit 1 set: pointwise kernel off too
 extern "C" int dm_set_splitk_inkernel(int on) { g_splitk_inkernel = on != 0; return DM_OK; }
@@ -1417,8 +568,7 @@ extern "C" int dm_conv_parity4(const DmConv* d4, dm_stream_t stream) {
             q.w4[i] = p[i].w; q.oy4[i] = p[i].oy0; q.ox4[i] = p[i].ox0; q.ooy4[i] = p[i].ooy; q.oox4[i] = p[i].oox;
         }
         hipStream_t st = (hipStream_t)stream;
-        if (d4[0].dtype == DM_BF16) return launch_tap4_tw<bf16, false>(q, st);
-        return launch_tap4_tw<f16, false>(q, st);
+        return launch_tap4_any(q, d4[0].dtype == DM_F16, false, st);
     }
     for (int i = 0; i < 4; ++i) {
         const int rc = dm_conv(d4 + i, stream);
