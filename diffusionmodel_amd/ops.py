@@ -24,6 +24,7 @@ from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, call, dt, ptr
 
 BN_EPS = 1e-5
 import os as _os
+BN_SLOTS_MAX_C = int(_os.environ.get("DM_BN_SLOTS_MAX_C", "256"))   # wider layers keep the partial rows + finalize launch: every workgroup of the consuming kernel folds slots x C doubles (128 KiB at C = 1024: 8x the tensor's own traffic on the 8x8 level, +6 us per launch against 2.6 us for the finalize launch)
 BN_SLOTS = int(_os.environ.get("DM_BN_SLOTS", "8"))          # train-mode BatchNorm statistics travel as [BN_SLOTS][C] accumulators folded by the consuming kernel (0: partial rows + finalize launches)
 _EPOCH = [0]          # bumped by the fused optimiser: invalidates packed-weight caches
 _CACHE = {}
@@ -493,7 +494,7 @@ class ConvBnAct(torch.autograd.Function):
         z = _empty((B, Ho, Wo, N), dtype, x)
         mean, rstd = _empty((N,), torch.float32, x), _empty((N,), torch.float32, x)
         out = _empty((B, Ho, Wo, N), dtype, x)
-        slots = BN_SLOTS if (train and N % (4 if dtype == torch.float32 else 8) == 0 and N <= 8192) else 0
+        slots = BN_SLOTS if (train and N % (4 if dtype == torch.float32 else 8) == 0 and N <= BN_SLOTS_MAX_C) else 0
         if train and slots:
             # the conv epilogue adds its per-tile column sums into [slots][N] accumulators; the normalise + activation kernel folds
             # them in its prologue (and updates the running statistics): no finalize launch in between
@@ -533,7 +534,7 @@ class ConvBnAct(torch.autograd.Function):
             g = g.contiguous()
             dbeta, dgamma = _empty((N,), torch.float32, g), _empty((N,), torch.float32, g)
             dz = _empty(z.shape, dtype, g)
-            slots = BN_SLOTS if (ctx.train and N % (4 if dtype == torch.float32 else 8) == 0 and N <= 8192) else 0
+            slots = BN_SLOTS if (ctx.train and N % (4 if dtype == torch.float32 else 8) == 0 and N <= BN_SLOTS_MAX_C) else 0
             if slots:      # sums of g and g*xhat as [slots][N] accumulators folded by the apply kernel (which also emits dbeta / dgamma)
                 pp = _gzeros((2, slots, 2 * N), g)           # [2][slots][N] doubles
                 call("dm_bn_act_bwd_reduce_slots", ptr(z), ptr(g), dt(dtype), M, N, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), spec.act,
