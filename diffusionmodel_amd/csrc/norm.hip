@@ -119,6 +119,9 @@ struct BnParams {
     }
 };
 
+#ifndef SLOT_THREADS
+#define SLOT_THREADS 512      // workgroup size of the slot-folding kernels: every workgroup folds slots x C doubles, so fewer, larger workgroups
+#endif
 // The same constants for the packed 16-bit GELU path (gelu_parts_fast2): xhat = z * rs + nmr, u = xhat * gm + bt on pairs of channels
 struct BnPair {
     f32x2 rs[4], nmr[4], gm[4], bt[4];
@@ -265,12 +268,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* z, T* y, int64
 // L2 — S = 8: 8 KiB at C = 128) instead of a separate finalize launch; workgroup 0 also publishes mean / rstd (the backward pass
 // needs them) and updates the running statistics (nn.BatchNorm2d: momentum, unbiased variance).
 template <typename T, int V>
-__global__ __launch_bounds__(256) void bn_act_fwd_slots_kernel(const T* z, T* y, int64_t nvec, int CV, const double* psum, const double* psq,
+__global__ __launch_bounds__(SLOT_THREADS) void bn_act_fwd_slots_kernel(const T* z, T* y, int64_t nvec, int CV, const double* psum, const double* psq,
                                                                int S, int M, float eps, float mom, const float* gamma, const float* beta,
                                                                int act, float* mean_out, float* rstd_out, float* rmean, float* rvar) {
     extern __shared__ float sstat[];                   // [2][C]
     const int C = CV * V;
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += SLOT_THREADS) {
         double s1 = 0.0, s2 = 0.0;
         for (int k = 0; k < S; ++k) { s1 += psum[(size_t)k * C + c]; s2 += psq[(size_t)k * C + c]; }
         const double mu = s1 / M;
@@ -290,8 +293,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_slots_kernel(const T* z, T* y,
         }
     }
     __syncthreads();
-    const int64_t G = ((int64_t)gridDim.x * 256 / CV) * CV;
-    const int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t G = ((int64_t)gridDim.x * SLOT_THREADS / CV) * CV;
+    const int64_t g0 = (int64_t)blockIdx.x * SLOT_THREADS + threadIdx.x;
     if (g0 >= G) return;
     BnParams<V> P;
     P.load((int)(g0 % CV) * V, C, sstat, sstat + C, gamma, beta);
@@ -426,12 +429,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* z, const T* 
 // bn_bwd_apply with the column sums folded in: p1 / p2 are the [S][C] slot accumulators of bn_bwd_reduce_kernel (slots mode);
 // workgroup 0 publishes dbeta = sum(g), dgamma = sum(g * xhat) — the parameter gradients — instead of a separate reduce launch.
 template <typename T, int V>
-__global__ __launch_bounds__(256) void bn_bwd_apply_slots_kernel(const T* z, const T* dy, T* dz, int64_t nvec, int CV, float invM,
+__global__ __launch_bounds__(SLOT_THREADS) void bn_bwd_apply_slots_kernel(const T* z, const T* dy, T* dz, int64_t nvec, int CV, float invM,
                                                                  const float* mean, const float* rstd, const float* gamma, const float* beta,
                                                                  int act, const double* p1, const double* p2, int S, float* dbeta, float* dgamma) {
     extern __shared__ float ssum[];                    // [2][C]
     const int C = CV * V;
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += SLOT_THREADS) {
         double a = 0.0, b = 0.0;
         for (int k = 0; k < S; ++k) { a += p1[(size_t)k * C + c]; b += p2[(size_t)k * C + c]; }
         ssum[c] = (float)a;
@@ -439,8 +442,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_slots_kernel(const T* z, con
         if (blockIdx.x == 0) { dbeta[c] = (float)a; dgamma[c] = (float)b; }
     }
     __syncthreads();
-    const int64_t G = ((int64_t)gridDim.x * 256 / CV) * CV;
-    const int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t G = ((int64_t)gridDim.x * SLOT_THREADS / CV) * CV;
+    const int64_t g0 = (int64_t)blockIdx.x * SLOT_THREADS + threadIdx.x;
     if (g0 >= G) return;
     const int c0 = (int)(g0 % CV) * V;
     BnParams<V> P;
@@ -952,7 +955,7 @@ extern "C" int dm_bn_act_fwd_slots(const void* z, void* y, int dtype, int M, int
         DM_CHECK_ARG(vec_ok<T>(C, z, y), "dm_bn_act_fwd_slots: C=%d must be a multiple of %d and the tensors 16-byte aligned", C, Elem<T>::VE);
         constexpr int V = Elem<T>::VE;
         const int64_t nvec = (int64_t)M * C / V;
-        hipLaunchKernelGGL((bn_act_fwd_slots_kernel<T, V>), dim3(stream_grid(nvec, C / V)), dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const T*)z, (T*)y,
+        hipLaunchKernelGGL((bn_act_fwd_slots_kernel<T, V>), dim3(cdiv(stream_grid(nvec, C / V) * 256, SLOT_THREADS)), dim3(SLOT_THREADS), 2 * C * sizeof(float), (hipStream_t)s, (const T*)z, (T*)y,
                            nvec, C / V, (const double*)psum, (const double*)psq, slots, M, eps, momentum, gamma, beta, act, mean, rstd, running_mean, running_var);
     });
     DM_LAUNCH_CHECK();
@@ -993,7 +996,7 @@ extern "C" int dm_bn_act_bwd_apply_slots(const void* z, const void* dy, void* dz
         DM_CHECK_ARG(vec_ok<T>(C, z, dy, dz), "dm_bn_act_bwd_apply_slots: C=%d must be a multiple of %d and the tensors 16-byte aligned", C, Elem<T>::VE);
         constexpr int V = Elem<T>::VE;
         const int64_t nvec = (int64_t)M * C / V;
-        hipLaunchKernelGGL((bn_bwd_apply_slots_kernel<T, V>), dim3(stream_grid(nvec, C / V)), dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const T*)z,
+        hipLaunchKernelGGL((bn_bwd_apply_slots_kernel<T, V>), dim3(cdiv(stream_grid(nvec, C / V) * 256, SLOT_THREADS)), dim3(SLOT_THREADS), 2 * C * sizeof(float), (hipStream_t)s, (const T*)z,
                            (const T*)dy, (T*)dz, nvec, C / V, invM, mean, rstd, gamma, beta, act, (const double*)p1, (const double*)p2, slots, dbeta, dgamma);
     });
     DM_LAUNCH_CHECK();
