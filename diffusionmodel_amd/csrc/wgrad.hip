@@ -548,8 +548,14 @@ struct WgHP {
     int ntiles, nchunks, blocks, splits, tiles_per_split;
 };
 
-template <typename T, int TW>
+// S2 = true: the 4x4 / stride-2 / pad-1 layer, one input-parity class (py, px) per workgroup.  With V(y, x) = X(2y + py, 2x + px) the
+// class's four taps (ky, kx) = (2 jy + 1 - py, 2 jx + 1 - px), j in {0, 1}^2, read V at (qy + jy - py, qx + jx - px): a 2x2-tap layer on a
+// sub-image of the output's size.  The halo is staged from row y0 - py / column -px on, so the taps sit at halo offsets (jy, jx) for
+// every class (compile-time fragment addresses); only the source addresses (pixels two apart, rows two apart) and the edge tests know
+// the class.  p.Hi / p.Wi are the OUTPUT (= dy = sub-image) extents.  The splits meet in dw through fp32 atomics.
+template <typename T, int TW, bool S2 = false>
 __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
+    constexpr int NTAP = S2 ? 4 : 9;
     // TW = 8 (8x8 images): a tile is TWO whole images side by side in the halo ([0 A 0][0 B 0], 10 columns apiece, HS = 24)
     constexpr int R = TW == 8 ? 8 : 128 / TW, HS = TW == 8 ? 24 : TW + 8, HR = R + 2, XP = HR * HS / 8;    // 36 / 30 / 30 / 30 halo pieces
     constexpr int HI = (TW == 8 ? 2 * HS : TW == 16 ? HS : 16) * 128;         // byte offset of the k-step's second 16 pixels in the halo
@@ -566,7 +572,9 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
     int idx = blockIdx.x;
     if ((G & 7) == 0) idx = (idx & 7) * (G >> 3) + (idx >> 3);
     const int block = idx % p.blocks, split = idx / p.blocks;
-    const int nbk = block / p.nchunks, chunk = block - nbk * p.nchunks;
+    const int cls = S2 ? block & 3 : 0, py = cls >> 1, px = cls & 1;      // S2: blocks = 4 classes x n tiles x chunks
+    const int blk = S2 ? block >> 2 : block;
+    const int nbk = blk / p.nchunks, chunk = blk - nbk * p.nchunks;
     const int n0 = nbk * 128, c0 = chunk * 64;
     const int C = p.C1 + p.C2;
     const bool first = c0 < p.C1;
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
     const int tiles_img = TW == 8 ? 1 : ((p.Hi * TW) >> 7) * tcols;
 
     const __amdgpu_buffer_rsrc_t rDY = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.ntiles * 128 * p.ldy * 2, WG_SRD);
-    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? p.in1 : p.in2), 0, p.ntiles * 128 * Cs * 2, WG_SRD);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? p.in1 : p.in2), 0, p.ntiles * 128 * Cs * 2 * (S2 ? 4 : 1), WG_SRD);
 
     // ---- staging: every per-lane quantity is ONE register per image; the piece index moves through scalar offsets
     // dy pieces 8 j + wave (4 rows x 256 B each): row & 7 does not depend on j, so neither does the lane's source column
@@ -604,7 +612,10 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
         const int hx = strip * 8 + (lane >> 3), s = lane & 7;
         const int lslot = ((((s >> 1) ^ ((hx >> 1) & 3)) << 1) | (s & 1));       // HS % 8 == 0: the swizzle follows hx only
         const int img = TW == 8 ? hx / 10 : 0;                                   // TW = 8: which of the tile's two images
-        const int x = TW == 8 ? hx - img * 10 - 1 : hx - 1;
+        const int x = (TW == 8 ? hx - img * 10 : hx) - (S2 ? px : 1);
+        if constexpr (S2)    // sub-image pixel (y, x) = input pixel (2 y + py, 2 x + px) of a (2 Hi) x (2 Wi) image
+            xv0 = (((hy0 - py) * 2 + py) * (2 * p.Wi) + img * (4 * 64) + 2 * x + px) * Cs * 2 + lslot * 16 + cin0 * 2;
+        else
         xv0 = ((hy0 - 1) * RW + img * 64 + x) * Cs * 2 + lslot * 16 + cin0 * 2;
         // column inside the tile; columns -1 and TW belong to the neighbouring column tile when there is one (xedge0: 1 = left, 2 = right)
         xok0 = (unsigned)x < (unsigned)TW && img < 2 && lslot * 8 < Cs;      // (a lone partial chunk, C < 64, reads zeros past C)
@@ -629,14 +640,18 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
         }
         const bool top = y0 == 0, bottom = y0 + R == p.Hi;                 // halo rows outside the image
         const bool has_left = x0 > 0, has_right = x0 + 64 < RW;            // neighbouring column tiles (TW = 64 only)
-        const int tbase = pix0 * Cs * 2;
+        // S2: the tile's first sub-image pixel (bimg, y0, 0) is input pixel (bimg, 2 y0, 0) — 4 input pixels per output pixel
+        const int tbase = S2 ? pix0 * 4 * Cs * 2 : pix0 * Cs * 2;
+        const int rstep = S2 ? 4 * p.Wi * Cs * 2 : RW * Cs * 2;            // one halo row down: two input rows of 2 Wi pixels
         if (halo_wave) {
 #pragma unroll
             for (int i = 0; i < RPG; ++i) {
                 const int hy = hy0 + i;
-                const bool row_ok = !((hy == 0 && top) || (hy == HR - 1 && bottom));
+                // S2: halo row hy is sub-image row y0 + hy - py; rows 0 .. R are used
+                const bool row_ok = S2 ? !((py == 1 && hy == 0 && top) || (py == 0 && hy == R && bottom) || hy > R)
+                                       : !((hy == 0 && top) || (hy == HR - 1 && bottom));
                 const bool col_ok = xok0 || (xedge0 == 1 && has_left) || (xedge0 == 2 && has_right);
-                const unsigned v = (col_ok && row_ok) ? (unsigned)(tbase + i * RW * Cs * 2 + xv0) : WG_OOB;
+                const unsigned v = (col_ok && row_ok) ? (unsigned)(tbase + i * rstep + xv0) : WG_OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_dst3)(sX + (hy * NC + strip) * 1024), 16, v, 0, 0, 0);
             }
         }
@@ -674,15 +689,15 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
         return __builtin_bit_cast(bf16x8, v);
     };
 
-    f32x4 acc[4][9];
+    f32x4 acc[4][NTAP];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NTAP; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // dbias[n] = sum over pixels of dy, straight from the dy image.  Every chunk of an n tile stages the same dy rows,
     // so the tiles are dealt round-robin over the chunks; a thread sums 4 columns x 8 rows of its tile.
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool want_bias = p.dbias != nullptr;
+    const bool want_bias = p.dbias != nullptr && cls == 0;      // (S2: the four classes stage the same dy rows)
     const int bcol = (tid & 31) * 4, brow = tid >> 5;
     int bphase = t_lo % p.nchunks;
 
@@ -698,13 +713,16 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
             const int koffA = ks * 32 * 256;
             const int koffB = (TW == 64 ? (ks >> 1) * HS + (ks & 1) * 32 : TW == 32 ? ks * HS : TW == 16 ? 2 * ks * HS : (ks & 1) * 4 * HS) * 128;
             const int im = TW == 8 ? ks >> 1 : 0;
-            bf16x8 fa[4], fb[9];
+            bf16x8 fa[4], fb[NTAP];
 #pragma unroll
             for (int it = 0; it < 4; ++it) fa[it] = tr_pair(sS + addrA[it] + koffA, 16 * 256);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) fb[t] = tr_pair(sS + addrB[t % 3][im] + koffB + ((t / 3) * HS) * 128, HI);
+            for (int t = 0; t < NTAP; ++t) {      // tap t = (row, column) offset in the halo: 3x3, or 2x2 for a stride-2 class
+                constexpr int TPR = S2 ? 2 : 3;
+                fb[t] = tr_pair(sS + addrB[t % TPR][im] + koffB + ((t / TPR) * HS) * 128, HI);
+            }
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
+            for (int t = 0; t < NTAP; ++t)
 #pragma unroll
                 for (int it = 0; it < 4; ++it) acc[it][t] = WMma<T>::run(fa[it], fb[t], acc[it][t]);
             // keep the k-steps apart: merged / hoisted halo reads push the kernel past 256 VGPRs, and a scratch reload in the
@@ -724,7 +742,21 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
     }
 
     // ---- flush: D[i = n][j = c] per tap; lane holds rows 4g..4g+3 (n), column il (c)
-    if (p.splits == 1) {                         // sole owner of its dw elements within the launch
+    if constexpr (S2) {                          // tap (jy, jx) of class (py, px) is weight tap (2 jy + 1 - py, 2 jx + 1 - px) of the 4x4 kernel
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + it * 16 + 4 * g + r;
+                if (n >= p.N || c0 + wc * 16 + il >= C) continue;
+                float* row = p.dw + (size_t)n * p.ldw + c0 + wc * 16 + il;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int ky = 2 * (t >> 1) + 1 - py, kx = 2 * (t & 1) + 1 - px;
+                    atomicAdd(row + (ky * 4 + kx) * C, acc[it][t][r]);
+                }
+            }
+    } else if (p.splits == 1) {                  // sole owner of its dw elements within the launch
 #pragma unroll
         for (int it = 0; it < 4; ++it)
 #pragma unroll
@@ -741,7 +773,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
 #pragma unroll
         for (int it = 0; it < 4; ++it)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) dst[(it * 9 + t) * 64] = acc[it][t];
+            for (int t = 0; t < NTAP; ++t) dst[(it * 9 + t) * 64] = acc[it][t];
     }
     if (want_bias) {                             // fold the 16 row groups in LDS, then one value per column and workgroup
         __syncthreads();
@@ -753,7 +785,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
             float v = 0.f;
 #pragma unroll
             for (int j = 0; j < 16; ++j) v += sb[j * 128 + tid];
-            if (p.splits > 1) p.ws[(size_t)p.splits * p.blocks * (128 * 9 * 64) + ((size_t)split * p.blocks + block) * 128 + tid] = v;
+            if (p.splits > 1 && !S2) p.ws[(size_t)p.splits * p.blocks * (128 * 9 * 64) + ((size_t)split * p.blocks + block) * 128 + tid] = v;
             else if (n0 + tid < p.N) atomicAdd(p.dbias + n0 + tid, v);
         }
     }
@@ -877,6 +909,49 @@ int launch_wgrad_halo(const WgHP& p, hipStream_t st) {
     return DM_OK;
 }
 
+template <typename T, int TW>
+int launch_wgrad_tap4(const WgHP& p, hipStream_t st) {
+    constexpr int bytes = 2 * WGH_STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_halo_kernel<T, TW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) { dm_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", bytes, hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad3x3_halo_kernel<T, TW, true>), dim3((unsigned)(p.blocks * p.splits)), dim3(512), bytes, st, p);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+// the 4x4 / stride-2 / pad-1 layer (new_scripy.py:229) on output rows of 32 / 16 pixels or 8x8 output images, one source, whole
+// 64-channel chunks: the halo-resident kernel in its S2 form (one input-parity class per workgroup, atomics into dw)
+int g_wgrad_tap4 = 1;
+int g_wgrad_tap4_blocks = 256;     // workgroups the pixel split aims at (each adds 32768 floats to dw through atomics)
+bool wgrad_tap4_plan(const DmWgrad* d, int64_t M, WgHP& hp) {
+    if (!g_wgrad_tap4 || !g_wgrad_halo || d->dtype == DM_F32 || d->T != 16 || d->KW != 4 || d->sy != 2 || d->sx != 2 || d->splitk > 0) return false;
+    if (d->ty != 1 || d->tx != 1 || d->oy0 != -1 || d->ox0 != -1 || d->C2 != 0 || d->C1 % 64 != 0) return false;
+    if (d->Hi != 2 * d->Hq || d->Wi != 2 * d->Wq || d->Ho != d->Hq || d->Wo != d->Wq || d->osy != 1 || d->osx != 1 || d->ooy != 0 || d->oox != 0) return false;
+    if (d->Wq == 8) {
+        if (d->Hq != 8 || d->B % 2 != 0) return false;
+    } else if ((d->Wq != 16 && d->Wq != 32) || (d->Hq * d->Wq) % 128 != 0) {
+        return false;
+    }
+    if (d->ldy % 8 != 0 || d->ldw != 16 * d->C1) return false;
+    if (M * 4 * d->C1 * 2 >= (1ll << 31) || M * d->ldy * 2 >= (1ll << 31)) return false;
+    if (((uintptr_t)d->dy & 15) || ((uintptr_t)d->in1 & 15)) return false;
+    hp.dy = (const char*)d->dy; hp.in1 = (const char*)d->in1; hp.in2 = nullptr; hp.dw = d->dw; hp.dbias = d->dbias; hp.ws = nullptr;
+    hp.B = d->B; hp.Hi = d->Hq; hp.Wi = d->Wq; hp.C1 = d->C1; hp.C2 = 0; hp.N = d->N; hp.ldy = d->ldy; hp.ldw = d->ldw;
+    hp.ntiles = (int)(M / 128);
+    hp.nchunks = d->C1 / 64;
+    hp.blocks = cdiv(d->N, 128) * hp.nchunks * 4;
+    int splits = g_wgrad_tap4_blocks / hp.blocks;
+    if (splits < 1) splits = 1;
+    if (splits > hp.ntiles) splits = hp.ntiles;
+    hp.tiles_per_split = cdiv(hp.ntiles, splits);
+    hp.splits = cdiv(hp.ntiles, hp.tiles_per_split);
+    return true;
+}
+
 // bf16 3x3 stride-1 pad-1 layer on whole 16/32/64-pixel rows, 64-channel chunks, identity dy mapping, 31-bit byte offsets.
 // Returns true (and fills hp) when the halo kernel can take the launch with the registered workspace.
 bool wgrad_halo_plan(const DmWgrad* d, int64_t M, WgHP& hp) {
@@ -959,8 +1034,14 @@ int launch_wgrad_pw(const WgPwP& q, int ntw, int ctw, hipStream_t st) {
     return DM_OK;
 }
 
-static int g_last_wgrad_path = 0;   // 1: the last dm_conv_wgrad launch went to wgrad3x3_halo_kernel, 2: to wgrad_pw_kernel
+static int g_last_wgrad_path = 0;   // 1: the last dm_conv_wgrad launch went to wgrad3x3_halo_kernel, 2: to wgrad_pw_kernel, 3: to the four-tap (S2) form of 1
 extern "C" int dm_last_wgrad_path(void) { return g_last_wgrad_path; }
+
+extern "C" int dm_set_wgrad_tap4(int on) {      // on > 1 also sets the workgroup target
+    g_wgrad_tap4 = on != 0;
+    if (on > 1) g_wgrad_tap4_blocks = on;
+    return DM_OK;
+}
 
 extern "C" int dm_set_wgrad_pw(int enable, int target_blocks, int min_pixels) {
     DM_CHECK_ARG(target_blocks >= 0 && target_blocks <= 65536, "dm_set_wgrad_pw: target_blocks %d out of range", target_blocks);
@@ -1008,6 +1089,18 @@ extern "C" int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream) {
         if (d->Wi == 32) return launch_wgrad_halo<bf16, 32>(hp, hst);
         if (d->Wi == 16) return launch_wgrad_halo<bf16, 16>(hp, hst);
         return launch_wgrad_halo<bf16, 8>(hp, hst);
+    }
+    if (wgrad_tap4_plan(d, M, hp)) {
+        g_last_wgrad_path = 3;
+        hipStream_t hst = (hipStream_t)stream;
+        if (d->dtype == DM_F16) {
+            if (d->Wq == 32) return launch_wgrad_tap4<f16, 32>(hp, hst);
+            if (d->Wq == 16) return launch_wgrad_tap4<f16, 16>(hp, hst);
+            return launch_wgrad_tap4<f16, 8>(hp, hst);
+        }
+        if (d->Wq == 32) return launch_wgrad_tap4<bf16, 32>(hp, hst);
+        if (d->Wq == 16) return launch_wgrad_tap4<bf16, 16>(hp, hst);
+        return launch_wgrad_tap4<bf16, 8>(hp, hst);
     }
     WgPwP q;
     int ntw = 0, ctw = 0;

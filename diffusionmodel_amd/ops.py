@@ -360,7 +360,7 @@ def _wgrad_call(dy, in1, in2, dw, dbias, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy
     kind = "conv_wgrad" if dtype != torch.float32 else "wgrad_f32"
     if PROFILE_META is not None:
         call("dm_conv_wgrad", C.byref(d))
-        halo = kind == "conv_wgrad" and L.load().dm_last_wgrad_path() == 1
+        halo = kind == "conv_wgrad" and L.load().dm_last_wgrad_path() in (1, 3)      # 3: the four-tap form of the same kernel (4x4 / stride 2)
         PROFILE_META.append(("wgrad_halo" if halo else kind, 2.0 * B * Hq * Wq * N * T * (C1 + C2), f"B{B} {Hi}x{Wi} C{C1}+{C2} N{N} T{T} s{sy}"))
     elif PROFILE is None or kind not in PROFILE_KINDS:
         call("dm_conv_wgrad", C.byref(d))

@@ -96,9 +96,13 @@ int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream);
 /* tuning knob: 1 = register staging, 2 = LDS-DMA, 3 (default) = 2 + the halo-resident kernel for 3x3 stride-1 layers
    (needs dm_set_workspace when the pixel range is split over workgroups; falls back to 2 without it) */
 int dm_set_wgrad_variant(int variant);
-/* 1 when the last dm_conv_wgrad launch used the halo-resident 3x3 kernel, 2 for the 1x1 kernel (wgrad_pw_kernel), 0 for the per-tap
+/* 1 when the last dm_conv_wgrad launch used the halo-resident 3x3 kernel, 2 for the 1x1 kernel (wgrad_pw_kernel), 3 for the four-tap form of the halo kernel (4x4 / stride 2), 0 for the per-tap
    kernels (measurement aid) */
 int dm_last_wgrad_path(void);
+/* on != 0 (default): the weight gradient of the 16-bit 4x4 / stride-2 / pad-1 layers (output rows of 32 / 16 pixels or 8x8 output
+   images) on the four-tap form of the halo-resident kernel; 0: per-tap kernel; > 1: also the workgroup count its pixel split aims at
+   (default 256).  dm_last_wgrad_path() reports 3.  Measurement knob. */
+int dm_set_wgrad_tap4(int on);
 /* enable != 0 (default): 16-bit 1x1 layers with min(N, C) in {32, 64, 128} and at least min_pixels output pixels take
    wgrad_pw_kernel; target_blocks > 0 sets the workgroup count its pixel split aims at for 4096-float output blocks (default 384;
    larger blocks get proportionally fewer workgroups: the same volume of fp32 atomics), 0 leaves it; min_pixels >= 0 sets the

@@ -682,6 +682,8 @@ def test_conv4x4s2_four_tap_halo_kernel_exact_integers(case, dtype):
     # (the input gradient reduces over Cout: whole 64-channel chunks go to the four-tap kernel, a ragged Cout to the gather kernel)
     assert lib.dm_last_conv_path() == (2 if Co % 64 == 0 else 0), "unexpected kernel for the input-gradient launches"
     assert torch.equal(nchw(xd.grad), xr.grad)
+    # the weight gradient: four-tap (S2) form of the halo-resident kernel on output rows of 32 / 16 pixels and 8x8 output images
+    assert lib.dm_last_wgrad_path() == (3 if H // 2 in (8, 16, 32) else 0), "unexpected kernel for the weight gradient"
     assert torch.equal(conv.weight.grad.cpu(), wr.grad)
     assert torch.equal(conv.bias.grad.cpu(), br.grad)
 
