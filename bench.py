@@ -121,14 +121,14 @@ def _timed(fn, n_timed, warm=1):
 def cpu_baseline(args):
     """The CPU oracle (a port of the reference's algorithm, oracle/unet_ref.py — the reference's files do not travel to the GPU
     box) on the host cores, SURVEY §8d / BASELINE.md §3: fp32, (a) the cfg-2 train step = DDPM.forward + backward + clip(1.0) +
-    AdamW at a reduced batch, scaled linearly to the benchmark batch, (b) the cfg-2 CFG sample step (n reduced likewise, w = 2),
+    AdamW AT THE STATED BATCH (B = 64; --cpu-batch reduces it and scales linearly), (b) the cfg-2 CFG sample step (n = 64, w = 2),
     (c) cfg-1 (MNIST net, B = 64, T = 400) train and sample steps in full.  The thread count is the best of a small sweep (the
     usable cores, and 64 / 32 when the box has more: 128 SMT threads oversubscribe oneDNN on this workload); 1 warm-up + >= 3
-    timed iterations per leg at that count."""
+    timed iterations per leg at that count (~30 s of CPU work for the train leg at 16 threads)."""
     from oracle import unet_ref as O
     torch.manual_seed(0)
     model, phys, usable = _cpu_info()
-    nf, S, Bs = args.n_feat, args.size, args.cpu_batch
+    nf, S, Bs = args.n_feat, args.size, (args.cpu_batch or args.batch)
     P = _rand_state(O.context_unet_spec(3, nf, 4, args.bottleneck_k))
     params = []
     for k, v in P.items():
@@ -205,11 +205,12 @@ def cpu_baseline(args):
     return {"value": round(1.0 / (t_train * scale), 5), "unit": "denoiser-steps/s (train, B=%d)" % args.batch, "cores": best,
             "kind": "port", "cpu_model": model, "physical_cores": phys, "usable_threads": usable, "cgroup_cpu_quota": quota,
             "thread_sweep_s_per_iter": {str(k): v for k, v in sweep.items()},
-            "sample": f"oracle train step (fwd+bwd+clip+AdamW) fp32 at B={Bs} x{scale:g} scaled, {n_it} timed iters at {best} threads "
-                      f"({', '.join('%.2f' % v for v in all_train)} s)",
+            "sample": f"oracle train step (fwd+bwd+clip+AdamW) fp32 at B={Bs}" + (f" x{scale:g} scaled" if scale != 1 else " (the stated batch, no scaling)")
+                      + f", 1 warm-up + {n_it} timed iters at {best} threads ({', '.join('%.2f' % v for v in all_train)} s)",
             "train_s_per_iter_at_sample_batch": round(t_train, 3),
             "sample_step": {"value": round(1.0 / (t_samp * scale), 5), "unit": "denoiser-steps/s (CFG sample, n=%d, w=2)" % args.batch,
-                            "sample": f"one sample() iteration at n={Bs} (denoiser batch {2 * Bs}) x{scale:g} scaled, {n_it} timed iters, {t_samp:.2f} s/iter"},
+                            "sample": f"one sample() iteration at n={Bs} (denoiser batch {2 * Bs})" + (f" x{scale:g} scaled" if scale != 1 else "")
+                                      + f", {n_it} timed iters, {t_samp:.2f} s/iter"},
             "cfg1_mnist": {"train_steps_per_s": round(1.0 / t_mt, 3), "sample_steps_per_s": round(1.0 / t_ms, 3),
                            "sample": f"MNIST net 28x28 F=64 T=400: train B=64 (fwd+bwd+Adam) {t_mt * 1e3:.0f} ms, sample n=60 (CFG batch 120) "
                                      f"{t_ms * 1e3:.0f} ms; {n_it} timed iters each, full size (no scaling)"}}
@@ -273,8 +274,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"])
     ap.add_argument("--sample-steps", dest="sample_steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
-    ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=8)
-    ap.add_argument("--cpu-iters", dest="cpu_iters", type=int, default=12)
+    ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=0, help="batch of the CPU-baseline legs (default: --batch, i.e. the stated B=64)")
+    ap.add_argument("--cpu-iters", dest="cpu_iters", type=int, default=3)
     ap.add_argument("--launch-selftest", dest="launch_selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one rank per GPU).  gloo is a REHEARSAL mode: the ranks may share devices (rank r uses device "

@@ -173,7 +173,86 @@ def ensure_workspace():
         _workspace = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device="cuda")
         if lib.dm_set_workspace(_workspace.data_ptr(), WORKSPACE_BYTES) != 0:
             raise DmError(lib.dm_last_error().decode())
+        device_guard()                 # first MFMA launch of this process on the device: is another process of ours on it?
     return _workspace
+
+
+# ---- one process per GPU, enforced per PROCESS (not only per torch.distributed job) ----------------------------------------
+# Workgroups that hold more than 64 KiB of LDS do not survive being preempted for ANOTHER PROCESS on this driver stack
+# (the compute-wave save area restores the first 64 KiB of LDS only — scripts/probes/lds_preempt.hip).
+# Every process that loads this library therefore holds a shared flock on a per-device lock file for its lifetime; a process
+# that finds (or later gets) company on its device switches itself to the <= 64-KiB kernel variants and says so on stderr.
+_guard = {"fd": None, "path": None, "shared": False, "checked": 0}
+LOCK_DIR = os.environ.get("DM_LOCK_DIR", "/tmp")
+
+
+def device_identity(index=None):
+    """A string that is the same for every process using the same physical GPU on this host (uuid / PCI address), else the
+    visible-device string + index."""
+    vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "")))
+    ident = None
+    if torch.cuda.is_available():
+        index = torch.cuda.current_device() if index is None else index
+        if index < torch.cuda.device_count():
+            props = torch.cuda.get_device_properties(index)
+            ident = str(getattr(props, "uuid", "")) or None
+            bus = getattr(props, "pci_bus_id", None)
+            if bus is not None:
+                ident = f"{ident}|bus{bus}|dev{getattr(props, 'pci_device_id', '')}|dom{getattr(props, 'pci_domain_id', '')}"
+    if ident is None:
+        ident = f"visible[{vis}]#{0 if index is None else index}"
+    return ident
+
+
+def _select_small_lds(reason):
+    import sys
+    lib = load()
+    if lib.dm_set_conv_variant(2) != 0 or lib.dm_set_wgrad_variant(2) != 0:
+        raise DmError(lib.dm_last_error().decode())
+    _guard["shared"] = True
+    print(f"[diffusionmodel_amd] pid {os.getpid()}: {reason}: selecting the <= 64-KiB-LDS kernel variants (DM_CONV_VARIANT=2, "
+          "DM_WGRAD_VARIANT=2); workgroups with more LDS are not preemption-safe between processes on this stack. "
+          "Use one process per GPU for full speed.", file=sys.stderr, flush=True)
+
+
+def device_guard(identity=None, recheck=False):
+    """Take (first call) or re-test (recheck=True) this process's claim on its device.  Returns True when the device is shared with
+    another process of this library — the library is then on its <= 64-KiB-LDS kernels.  DM_DEVICE_GUARD=0 switches the guard off
+    (several processes on one GPU with the full-size kernels: at your own risk)."""
+    import fcntl
+    if os.environ.get("DM_DEVICE_GUARD", "1") == "0":
+        return False
+    if _guard["shared"]:
+        return True
+    if _guard["fd"] is None:
+        import hashlib
+        ident = device_identity() if identity is None else identity
+        path = os.path.join(LOCK_DIR, "diffusionmodel_amd.gpu-" + hashlib.sha1(str(ident).encode()).hexdigest()[:16] + ".lock")
+        try:
+            fd = os.open(path, os.O_CREAT | os.O_RDWR, 0o666)
+        except OSError:
+            return False                                   # no writable lock directory: nothing to go by
+        _guard["fd"], _guard["path"] = fd, path
+        try:
+            fcntl.flock(fd, fcntl.LOCK_SH | fcntl.LOCK_NB)
+        except OSError:                                    # somebody is probing with an exclusive lock right now: we are not alone
+            fcntl.flock(fd, fcntl.LOCK_SH)
+            _select_small_lds("another process is using this GPU")
+            return True
+    fd = _guard["fd"]
+    _guard["checked"] += 1
+    try:                                                   # sole holder <=> the shared lock can be made exclusive
+        fcntl.flock(fd, fcntl.LOCK_EX | fcntl.LOCK_NB)
+        fcntl.flock(fd, fcntl.LOCK_SH)
+        return False
+    except OSError:
+        fcntl.flock(fd, fcntl.LOCK_SH)                     # (a failed conversion may drop the lock: take it again)
+        _select_small_lds("another process " + ("started using" if recheck else "is using") + " this GPU")
+        return True
+
+
+def device_is_shared():
+    return _guard["shared"]
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)

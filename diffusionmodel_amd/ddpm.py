@@ -157,6 +157,8 @@ class DDPM(_HipBlock):
         n_sample) of a class-cycled batch of total_samples — their classes and their slice of the in-kernel noise
         stream — so the shards of any world size concatenate to the images of the single-process call with that seed."""
         net = self.nn_model
+        ops.L.ensure_workspace()
+        ops.L.device_guard(recheck=True)             # one process per GPU (the halo kernels' LDS does not survive preemption between processes)
         total = n_sample if total_samples is None else int(total_samples)
         if total % self.n_classes:
             raise DmError(f"n_sample={total} must be a multiple of n_classes={self.n_classes} (new_scripy.py:448)")

@@ -85,7 +85,7 @@ class GraphedTrainStep:
     """mode="graph": replay the instantiated hipGraph.  mode="plan": the captured graph is never instantiated; its kernel /
     memset nodes are read back once (dm_plan_from_graph) and every step re-issues them from C as plain stream launches
     (dm_plan_run: one ctypes call per step) — the host cost of a graph replay without the graph executor's per-node device
-    cost, and segments (dm_plan_marker) between which the host can run collectives (parallel.PlannedDataParallelStep)."""
+    cost, and segments (dm_plan_marker) between which the host can run collectives (parallel.OverlappedGradReducer.replay)."""
 
     def __init__(self, ddpm, opt, x, c, attn_mask, warmup=2, mode="graph", body=None, runner=None):
         if not x.is_cuda:
@@ -95,6 +95,8 @@ class GraphedTrainStep:
         if runner is not None and mode != "plan":
             raise DmError("GraphedTrainStep: a segment runner needs mode='plan'")
         self.ddpm, self.opt, self.mode, self._body, self._runner, self.plan = ddpm, opt, mode, body, runner, None
+        L.ensure_workspace()
+        self._shared_at_capture, self._fallback_eager = L.device_guard(recheck=True), False
         self.x, self.c, self.am = x.clone(), c.clone(), attn_mask.clone()
         self._specs = [sp for m in ddpm.modules() if isinstance(m, _HipBlock) for sp in m._specs()]
         dev = x.device
@@ -166,6 +168,18 @@ class GraphedTrainStep:
             self.graph.replay()
 
     def __call__(self, x=None, c=None, attn_mask=None):
+        if not self._shared_at_capture and L.device_guard(recheck=True):
+            # another process started using this GPU: the captured launches hold > 64 KiB of LDS per workgroup, which is not
+            # preemption-safe between processes here (_lib.device_guard) -> from now on the step is issued eagerly, on the small kernels
+            self._fallback_eager = True
+        if self._fallback_eager:
+            if x is not None:
+                self.x.copy_(x, non_blocking=True)
+            if c is not None:
+                self.c.copy_(c, non_blocking=True)
+            if attn_mask is not None:
+                self.am.copy_(attn_mask, non_blocking=True)
+            return self._eager()
         if x is not None:
             self.x.copy_(x, non_blocking=True)
         if c is not None:

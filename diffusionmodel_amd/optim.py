@@ -159,6 +159,7 @@ class FusedAdamW(torch.optim.Optimizer):
         the loss scale; the kernel unscales them, a step with inf / nan gradients is skipped and the scale adapts — all on the device."""
         if closure is not None:
             raise DmError("FusedAdamW.step does not take a closure")
+        ops.L.device_guard(recheck=True)             # one process per GPU, re-tested every step (two system calls)
         self.gather_grads()
         self._step += 1
         self.sync_hyper()

@@ -39,17 +39,8 @@ def init_from_env(backend=None, force=False):
 def _device_identity(local):
     """(host, physical device) of the HIP device this rank will use — enough to tell whether two ranks share one GPU."""
     import socket
-    vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "")))
-    ident = None
-    if torch.cuda.is_available() and local < torch.cuda.device_count():
-        props = torch.cuda.get_device_properties(local)
-        ident = str(getattr(props, "uuid", "")) or None
-        bus = getattr(props, "pci_bus_id", None)
-        if bus is not None:
-            ident = f"{ident}|bus{bus}|dev{getattr(props, 'pci_device_id', '')}|dom{getattr(props, 'pci_domain_id', '')}"
-    if ident is None:
-        ident = f"visible[{vis}]#{local}"
-    return socket.gethostname(), ident
+    from ._lib import device_identity
+    return socket.gethostname(), device_identity(local)
 
 
 def guard_shared_device(local, group=None, identity=None):
@@ -70,6 +61,7 @@ def guard_shared_device(local, group=None, identity=None):
             lib = L.load()
             if lib.dm_set_conv_variant(2) != 0 or lib.dm_set_wgrad_variant(2) != 0:
                 raise DmError(lib.dm_last_error().decode())
+            L._guard["shared"] = True                 # (the per-process guard has nothing left to do)
         if dist.get_rank(group) == 0:
             print(f"[diffusionmodel_amd] {len(everyone)} ranks share {len(set(everyone))} device(s): selecting the <= 64-KiB-LDS "
                   "kernel variants (DM_CONV_VARIANT=2, DM_WGRAD_VARIANT=2); workgroups with more LDS are not preemption-safe "
@@ -189,11 +181,12 @@ class OverlappedGradReducer:
         for b, bk in enumerate(self.buckets):
             for i in bk["slots"]:
                 self._bucket_of_slot[i] = b
-        self._learned, self._seen = False, set()
+        self._learned, self._seen, self._seen_seq = False, set(), []
         self._bucket_of, self._need = {}, [0] * len(self.buckets)
         self._small, self._small_key, self._small_total = [], None, 0
         self._packed, self._tables = None, None
         self._pending, self._launched, self._works = [], [], []
+        self._order, self._learned_order = [], None       # bucket launch order of this step / of the last complete overlapped step
 
     # ---- per step ----------------------------------------------------------------------------
     def begin(self, capture=False):
@@ -203,12 +196,14 @@ class OverlappedGradReducer:
         self._pending = list(self._need)
         self._launched = [False] * len(self.buckets)
         self._works = []
-        self._seen = set()
+        self._seen, self._seen_seq = set(), []
+        self._order = []
         self._ops.ON_WGRAD = self._notify if self.active else None
 
     def _notify(self, p):
-        if not self._learned:                         # observation step: just record who reports
+        if not self._learned:                         # observation step: just record who reports, and in which order
             self._seen.add(id(p))
+            self._seen_seq.append(id(p))
             return
         b = self._bucket_of.get(id(p))
         if b is None or self._launched[b]:
@@ -219,6 +214,7 @@ class OverlappedGradReducer:
 
     def _launch(self, b):
         self._launched[b] = True
+        self._order.append(b)
         if getattr(self, "_capture", False):           # recorded as a segment boundary; replay() runs the collective there
             from ._lib import call
             call("dm_plan_marker", int(b))
@@ -260,12 +256,21 @@ class OverlappedGradReducer:
         tin, tout, n_rows = self._tables
         call("dm_scatter_copy", ptr(tin if to_packed else tout), n_rows, 0)
 
-    def finish(self):
+    def finish(self, idle=False):
         """Call after backward: reduces what is left (buckets nobody completed, the small parameters) and makes the summed
-        gradients visible to the launch stream.  Folds the autograd `.grad` tensors into the flat buffer on the way."""
+        gradients visible to the launch stream.  Folds the autograd `.grad` tensors into the flat buffer on the way.
+        idle=True: this rank ran NO backward pass under the reducer for this step (short tail of an epoch: its peers did) — it
+        issues the same collectives in the order an overlapped step issues them, contributing whatever its buffers hold."""
         self._ops.ON_WGRAD = None
         if not self.active:
             return
+        if idle:
+            if getattr(self, "_capture", False) or not self._learned or self._small_key is None:
+                raise DmError("OverlappedGradReducer.finish(idle=True): needs one completed eager step on this rank first "
+                              "(the first optimiser step of a run cannot be a short tail)")
+            for b in (self._learned_order or range(len(self.buckets))):
+                if not self._launched[b]:
+                    self._launch(b)
         if getattr(self, "_capture", False):
             from ._lib import call
             call("dm_plan_marker", self.MARK_BACKWARD_DONE)
@@ -285,9 +290,21 @@ class OverlappedGradReducer:
                 self._need[b] += 1
             self._need = [n if n > 0 else 1 << 30 for n in self._need]     # a bucket nobody reports into waits for finish()
             self._learned = True
+            # the order in which an overlapped step will launch the buckets (notification order, then the rest by index): what a
+            # rank without a backward pass of its own (finish(idle=True)) must follow so that the collectives pair up
+            pend, order = list(self._need), []
+            for k in self._seen_seq:
+                b = self._bucket_of.get(k)
+                if b is not None and b not in order:
+                    pend[b] -= 1
+                    if pend[b] <= 0:
+                        order.append(b)
+            self._learned_order = order + [b for b in range(len(self.buckets)) if b not in order]
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
+        if not idle and len(self._order) == len(self.buckets):
+            self._learned_order = list(self._order)
         # the early reductions summed zeros in the `.grad` slots; nothing else may touch those slots until they are done
         for w in self._works:
             w.wait()
@@ -296,6 +313,8 @@ class OverlappedGradReducer:
         self._works = []
         # the parameters whose gradient is an autograd `.grad` right now are exactly the slots the buckets have not covered
         small = [(off, n) for (p, off, n) in self.opt._slots if p.grad is not None]
+        if idle and not small:
+            small = list(self._small)                 # nothing of its own to add: the learned set, so that the packed sizes agree
         key = tuple(small)
         if key != self._small_key:
             self._small, self._small_key, self._tables = small, key, None
@@ -339,6 +358,53 @@ class OverlappedGradReducer:
                 dist.all_reduce(self._packed, op=dist.ReduceOp.SUM, group=self.group)
             elif m != -1:
                 raise DmError(f"OverlappedGradReducer.replay: unknown plan marker {m}")
+
+
+def launch_ranks(script, argv, n, extra_env=None):
+    """Start `n` fresh child processes of `script` — one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set — and return
+    the first non-zero exit code (0 if none).  The CALLER must not have made a GPU call (torch.cuda.device_count() is fine on this
+    image): it only waits.  Rank 0 inherits stdout, the other ranks' stdout goes to stderr."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    codes = [p.wait() for p in procs]
+    bad = [c for c in codes if c]
+    return bad[0] if bad else 0
+
+
+def broadcast_buffers(module, src=0, group=None):
+    """Rank `src`'s floating-point buffers (BatchNorm running statistics: every rank keeps the statistics of ITS micro-batches,
+    SURVEY 8e) to every rank — before a validation / sampling pass whose result must not depend on the rank."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    bufs = [b for b in module.buffers() if b.is_floating_point()]
+    if not bufs:
+        return
+    flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+    if flat.is_cuda and dist.get_backend(group) != "nccl":
+        host = flat.cpu()
+        dist.broadcast(host, src=src, group=group)
+        flat = host.to(flat.device)
+    else:
+        dist.broadcast(flat, src=src, group=group)
+    o = 0
+    with torch.no_grad():
+        for b in bufs:
+            b.copy_(flat[o:o + b.numel()].view_as(b))
+            o += b.numel()
+    for m in module.modules():                  # eval-mode folds are cached per statistics epoch
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m._stat_epoch = getattr(m, "_stat_epoch", 0) + 1
 
 
 def broadcast_parameters(flat_params, src=0, group=None):

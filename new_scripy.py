@@ -22,6 +22,8 @@ import numpy as np
 import torch
 
 from diffusionmodel_amd import Cfg, ContextUnet, DDPM, FusedAdamW
+from diffusionmodel_amd import parallel
+from diffusionmodel_amd.train import StridedBatchSampler, TrainEngine, reduce_mean_scalar
 
 
 class SyntheticCrackDataset(torch.utils.data.Dataset):
@@ -133,13 +135,48 @@ def _jsonable(v):
     return v
 
 
-def train_model(n_classes=4, n_train=64, n_val=16, max_epochs=None, device="cuda:0", quiet=False, data_root=None):
-    """new_scripy.py:659-943.  Returns (ddpm, per-epoch history)."""
+def _dist_setup(device):
+    """(rank, world, device): joins the process group torchrun / --gpus N described (RANK, WORLD_SIZE, MASTER_*), one process per
+    GPU, `nccl` = RCCL (DM_DIST_BACKEND=gloo: rehearsal on fewer devices, ranks then share them).  Without WORLD_SIZE: (0, 1, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        Cfg.WORLD_SIZE = 1
+        return 0, 1, device
+    backend = os.environ.get("DM_DIST_BACKEND") or None
+    if backend == "gloo" and torch.cuda.is_available():
+        os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+    rank, world, local = parallel.init_from_env(backend)
+    torch.cuda.set_device(local)
+    Cfg.WORLD_SIZE = world
+    return rank, world, f"cuda:{local}"
+
+
+def _sample_all_ranks(ddpm, n, size, device, w, seed, world, **kw):
+    """ddpm.sample over the ranks of the job: shards of n / world samples with their slice of the noise stream and one gather
+    (parallel.sample_sharded) when n divides; otherwise every rank computes all n from the same seed (identical images)."""
+    if world > 1 and n % world == 0:
+        return parallel.sample_sharded(ddpm, n, size, device, guide_w=w, seed=seed, **kw)
+    return ddpm.sample(n_sample=n, size=size, device=device, guide_w=w, seed=seed if world > 1 else None, **kw)
+
+
+def train_model(n_classes=4, n_train=64, n_val=16, max_epochs=None, device="cuda:0", quiet=False, data_root=None, use_plan=True):
+    """new_scripy.py:659-943.  Returns (ddpm, per-epoch history).
+
+    Under torchrun / `--gpus N` (WORLD_SIZE > 1) the loop is data parallel, one process per GPU: micro-batch m of the epoch goes to
+    rank m % world, an optimiser step covers world * ceil(ACCUM_STEPS / world) micro-batches weighed like the reference's
+    accumulation group (:786, :795-803; diffusionmodel_amd/train.py), the flat gradient is all-reduced over RCCL in buckets that
+    overlap the backward pass, validation batches are sharded the same way, rank 0's BatchNorm statistics are the model's
+    (broadcast before every validation / sampling pass and the ones checkpointed), periodic sampling is sharded over the ranks
+    and only rank 0 writes files.  A step that is one fixed-shape micro-batch per rank runs as a launch plan."""
     from diffusionmodel_amd.metrics import ImageMetrics
-    say = (lambda *a: None) if quiet else print
-    os.makedirs(Cfg.SAVE_DIR, exist_ok=True)
+    rank, world, device = _dist_setup(device)
+    chief = rank == 0
+    say = (lambda *a: None) if (quiet or not chief) else print
     metrics_dir = os.path.join(Cfg.SAVE_DIR, "metrics")                                    # :664-665
-    os.makedirs(metrics_dir, exist_ok=True)
+    if chief:
+        os.makedirs(Cfg.SAVE_DIR, exist_ok=True)
+        os.makedirs(metrics_dir, exist_ok=True)
     metrics_log = {"train_loss": [], "val_loss": [], "img_metrics": [], "lr": []}          # :668-673
     guide_scales = Cfg.GUIDE_SCALES
     img_metrics = ImageMetrics(device=device)
@@ -156,33 +193,52 @@ def train_model(n_classes=4, n_train=64, n_val=16, max_epochs=None, device="cuda
     else:
         train_ds = SyntheticCrackDataset(n_train, S, n_classes, seed=0)
         val_ds = SyntheticCrackDataset(n_val, S, n_classes, seed=1)
-    # no drop_last: the reference flushes a short tail group instead (:795)
-    train_dl = torch.utils.data.DataLoader(train_ds, batch_size=Cfg.BATCH_SIZE, shuffle=True,
-                                           num_workers=Cfg.NUM_WORKERS if data_root else 0)
-    val_dl = torch.utils.data.DataLoader(val_ds, batch_size=Cfg.BATCH_SIZE)
+    # no drop_last: the reference flushes a short tail group instead (:795).  One seeded permutation per epoch, shared by the ranks
+    seed = [int(torch.initial_seed()) & 0x7FFFFFFF]
+    if world > 1:
+        torch.distributed.broadcast_object_list(seed, src=0)
+    train_bs = StridedBatchSampler(len(train_ds), Cfg.BATCH_SIZE, rank, world, shuffle=True, seed=seed[0])
+    val_bs = StridedBatchSampler(len(val_ds), Cfg.BATCH_SIZE, rank, world, shuffle=False)
+    train_dl = torch.utils.data.DataLoader(train_ds, batch_sampler=train_bs, num_workers=Cfg.NUM_WORKERS if data_root else 0)
+    val_dl = torch.utils.data.DataLoader(val_ds, batch_sampler=val_bs)
+    torch.manual_seed(seed[0])                                                             # identical initial weights on every rank
     ddpm = build_model(n_classes, device)
+    ddpm.rng_seed = seed[0] + 7919 * rank                                                  # every rank draws its own t / noise / keep masks
     shadow = ddpm.compute_dtype if ddpm.compute_dtype != torch.float32 else torch.bfloat16
     optim = FusedAdamW(ddpm.parameters(), lr=Cfg.LR, weight_decay=Cfg.WD, max_grad_norm=1.0, shadow_dtype=shadow)   # :715-719 + clip of :798
+    if world > 1:
+        from diffusionmodel_amd import ops as _ops
+        parallel.broadcast_parameters(optim.flat_p)
+        optim.refresh_shadow()
+        _ops.bump_weight_epoch()
+        parallel.broadcast_buffers(ddpm)
     scheduler = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(optim, T_0=10, T_mult=2, eta_min=3e-5)
-    early_stop = EarlyStop(verbose=not quiet)
+    engine = TrainEngine(ddpm, optim, accum_steps=Cfg.ACCUM_STEPS, use_plan=use_plan)
+    if world > 1 and engine.G != Cfg.ACCUM_STEPS:
+        say(f"[data parallel] {world} ranks, ACCUM_STEPS={Cfg.ACCUM_STEPS}: an optimiser step covers {engine.G} micro-batches "
+            f"({engine.local_accum} per rank)")
+    if train_bs.n_batches < world:
+        raise SystemExit(f"{train_bs.n_batches} micro-batches per epoch cannot feed {world} ranks")
+    early_stop = EarlyStop(verbose=not quiet and chief)
     n_epoch = Cfg.N_EPOCH if max_epochs is None else max_epochs
 
     def save_ckpt(epoch, loss, is_best=False):                                             # :730-744
+        if not chief:
+            return
         path = os.path.join(Cfg.SAVE_DIR, "best_model.pt" if is_best else f"ckpt_ep{epoch}.pt")
         torch.save({"epoch": epoch, "model_state_dict": ddpm.state_dict(), "optimizer_state_dict": optim.state_dict(),
                     "scheduler_state_dict": scheduler.state_dict(), "loss": loss, "metrics": _jsonable(metrics_log)}, path)
         say(f'Saved {"best " if is_best else ""}checkpoint: {path}')
 
-    # validation samples for the periodic quality evaluation (:746-765)
+    # validation samples for the periodic quality evaluation (:746-765); every rank collects the same ones (it shards the sampling)
     eval_samples, eval_count = [], min(32, len(val_ds))
     per_class = max(2, eval_count // n_classes)
     counts = {i: 0 for i in range(n_classes)}
-    for x, c, _ in val_dl:
-        for i in range(len(c)):
-            ci = int(c[i])
-            if counts[ci] < per_class and len(eval_samples) < eval_count:
-                eval_samples.append((x[i].to(device), ci))
-                counts[ci] += 1
+    for i in range(len(val_ds)):
+        x_i, c_i = val_ds[i][0], int(val_ds[i][1])
+        if counts[c_i] < per_class and len(eval_samples) < eval_count:
+            eval_samples.append((x_i.to(device), c_i))
+            counts[c_i] += 1
         if sum(counts.values()) >= eval_count:
             break
     say(f"Collected {len(eval_samples)} samples for evaluation")
@@ -191,33 +247,37 @@ def train_model(n_classes=4, n_train=64, n_val=16, max_epochs=None, device="cuda
     for ep in range(n_epoch):
         t0 = time.time()
         ddpm.train()
-        optim.zero_grad()
+        train_bs.set_epoch(ep)
         train_loss_ema, losses = None, []
-        for it, (x, c, am) in enumerate(train_dl):
-            loss = ddpm(x.to(device), c.long().to(device), to_mask(am)) / Cfg.ACCUM_STEPS   # :784-786
-            losses.append(loss.detach())
-            ddpm.scaler.scale(loss).backward()                                             # :792 (live in float16 mode only)
-            if (it + 1) % Cfg.ACCUM_STEPS == 0 or it + 1 == len(train_dl):                 # :795: also flush a short tail group
-                ddpm.scaler.unscale_(optim)                                                # :797 (the fused kernel unscales + clips 1.0, :798)
-                ddpm.scaler.step(optim)                                                    # :800: skipped on the device when a gradient is inf / nan
-                ddpm.scaler.update()                                                       # :801
-                optim.zero_grad()                                                          # :803
-        vals = [float(v) * Cfg.ACCUM_STEPS for v in torch.stack(losses).tolist()]          # one readback per epoch (:789 reads every step)
+        it = iter(train_dl)
+        for s in range(train_bs.slots):
+            if train_bs.mine[s] is None:                                                   # short tail: the peers have a micro-batch here
+                engine.idle_slot()
+                continue
+            x, c, am = next(it)
+            # :784-803 — loss / ACCUM, scaled backward, and at the end of a group (or of the epoch, :795) unscale + clip + AdamW
+            losses.append(engine.micro_batch(x.to(device), c.long().to(device), to_mask(am), last_in_epoch=s == train_bs.slots - 1))
+        vals = [float(v) * engine.loss_div for v in torch.stack(losses).reshape(-1).tolist()]   # one readback per epoch (:789 reads every step)
+        if world > 1:                                 # the epoch's micro-batch losses in micro-batch order, on every rank
+            allv = [None] * world
+            torch.distributed.all_gather_object(allv, vals)
+            vals = [allv[m % world][m // world] for m in range(train_bs.n_batches)]
         for v in vals:
             train_loss_ema = v if train_loss_ema is None else 0.95 * train_loss_ema + 0.05 * v          # :806-809
         tr = sum(vals) / len(vals)
         metrics_log["train_loss"].append(tr)
         metrics_log["lr"].append(scheduler.get_last_lr()[0])
+        parallel.broadcast_buffers(ddpm)              # rank 0's BatchNorm statistics are the model's
         ddpm.eval()                                                                        # :818-835
         with torch.no_grad():
             vl = [ddpm(x.to(device), c.long().to(device), to_mask(am)) for x, c, am in val_dl]
-        va = float(torch.stack(vl).mean()) if len(vl) == 1 else sum(float(v) for v in vl) / len(vl)
+        va = reduce_mean_scalar(float(torch.stack(vl).sum()) if vl else 0.0, len(vl), device)
         metrics_log["val_loss"].append(va)
         history.append({"epoch": ep, "train_loss": tr, "val_loss": va, "lr": optim.param_groups[0]["lr"], "time": time.time() - t0})
         say(f"epoch {ep}: train {tr:.4f} val {va:.4f} lr {optim.param_groups[0]['lr']:.2e} ({time.time() - t0:.1f}s)")
-        is_best = early_stop(va, ddpm, ep)                                                 # :838
+        is_best = early_stop(va, ddpm if chief else None, ep)                              # :838 (the same decision on every rank)
         if early_stop.early_stop:                                                          # :839-845
-            if early_stop.best_state:
+            if chief and early_stop.best_state:
                 torch.save(early_stop.best_state, os.path.join(Cfg.SAVE_DIR, "best_model_early.pt"))
             break
         scheduler.step()                                                                   # per epoch, :848
@@ -225,10 +285,12 @@ def train_model(n_classes=4, n_train=64, n_val=16, max_epochs=None, device="cuda
             ddpm.eval()
             n_gen = len(eval_samples) // n_classes * n_classes      # sample() needs a multiple of n_classes (:448)
             real = torch.stack([s[0] for s in eval_samples])[:n_gen]
-            for w in guide_scales:
+            for gi, w in enumerate(guide_scales):
                 if n_gen == 0:
                     break
-                x_gen = ddpm.sample(n_sample=n_gen, size=(Cfg.IN_CH, S, S), device=device, guide_w=w)
+                x_gen = _sample_all_ranks(ddpm, n_gen, (Cfg.IN_CH, S, S), device, w, seed[0] + 1000 * ep + gi + 1, world)
+                if not chief:
+                    continue
                 grid_path = os.path.join(Cfg.SAVE_DIR, f"img_ep{ep}_w{w}.png")
                 save_samples(x_gen, grid_path, nrow=4)
                 try:
@@ -242,12 +304,23 @@ def train_model(n_classes=4, n_train=64, n_val=16, max_epochs=None, device="cuda
             save_ckpt(ep, train_loss_ema)
         if is_best:                                                                        # :900-901
             save_ckpt(ep, va, is_best=True)
-        with open(os.path.join(metrics_dir, f"metrics_ep{ep}.json"), "w") as f:            # :904-919
-            json.dump(_jsonable(metrics_log), f, indent=2)
+        if chief:
+            with open(os.path.join(metrics_dir, f"metrics_ep{ep}.json"), "w") as f:        # :904-919
+                json.dump(_jsonable(metrics_log), f, indent=2)
     save_ckpt(n_epoch - 1, train_loss_ema)                                                 # final model, :931
-    if early_stop.best_state and early_stop.best_state["model_state_dict"] is not None:    # :934-936
+    if world > 1:                                     # every rank leaves with the best weights rank 0 kept (:934-936)
+        have = [bool(early_stop.best_state and early_stop.best_state["model_state_dict"] is not None)]
+        torch.distributed.broadcast_object_list(have, src=0)
+        if have[0]:
+            if chief:
+                ddpm.load_state_dict(early_stop.best_state["model_state_dict"])
+            parallel.broadcast_parameters(optim.flat_p)
+            parallel.broadcast_buffers(ddpm)
+            optim.refresh_shadow()
+    elif early_stop.best_state and early_stop.best_state["model_state_dict"] is not None:  # :934-936
         ddpm.load_state_dict(early_stop.best_state["model_state_dict"])
         optim.refresh_shadow()
+    ddpm.train_engine = engine
     return ddpm, history
 
 
@@ -267,6 +340,8 @@ def gen_samples(ckpt_path, n_samples_per_class=Cfg.SAMPLES_PER_CLASS, guide_scal
     images of `data_root`) unless eval_quality is off."""
     guide_scales = Cfg.GUIDE_SCALES if guide_scales is None else guide_scales
     S = Cfg.IMG_SIZE
+    rank, world, device = _dist_setup(device)         # torchrun / --gpus N: the samples of every guide scale are sharded over the ranks
+    chief = rank == 0
     ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=True)
     sd = ckpt["model_state_dict"] if isinstance(ckpt, dict) and "model_state_dict" in ckpt else ckpt   # :975-990
     dataset = None
@@ -279,11 +354,15 @@ def gen_samples(ckpt_path, n_samples_per_class=Cfg.SAMPLES_PER_CLASS, guide_scal
     class_names = list(class_names) if class_names else [f"class{i}" for i in range(n_classes)]
     ddpm = build_model(n_classes, device, drop_prob=0.0)
     ddpm.load_state_dict(sd)
-    if isinstance(ckpt, dict) and "metrics" in ckpt:
+    if chief and isinstance(ckpt, dict) and "metrics" in ckpt:
         print("Checkpoint contains training metrics")
     ddpm.eval()
-    samples_dir = os.path.join(Cfg.SAMPLE_DIR, f"samples_{int(time.time())}")              # :996-998
-    os.makedirs(samples_dir, exist_ok=True)
+    stamp = [int(time.time())]
+    if world > 1:
+        torch.distributed.broadcast_object_list(stamp, src=0)
+    samples_dir = os.path.join(Cfg.SAMPLE_DIR, f"samples_{stamp[0]}")                      # :996-998
+    if chief:
+        os.makedirs(samples_dir, exist_ok=True)
     if eval_quality and real_images is None and dataset is not None:                       # :1001-1029
         need = n_samples_per_class * min(n_classes, 4)
         real_images = torch.stack([dataset[i][0] for i in range(min(need, len(dataset)))])
@@ -292,10 +371,13 @@ def gen_samples(ckpt_path, n_samples_per_class=Cfg.SAMPLES_PER_CLASS, guide_scal
     from diffusionmodel_amd.metrics import ImageMetrics
     img_metrics = ImageMetrics(device=device)
     results, quality = {}, {}
-    for w in guide_scales:
+    for gi, w in enumerate(guide_scales):
         n_sample = n_samples_per_class * n_classes
-        x_gen = ddpm.sample(n_sample, (Cfg.IN_CH, S, S), device, guide_w=w, use_graph=use_graph)
+        x_gen = _sample_all_ranks(ddpm, n_sample, (Cfg.IN_CH, S, S), device, w, stamp[0] + gi, world, use_graph=use_graph)   # :1036-1041
         grid_path = os.path.join(samples_dir, f"samples_g{w}.png")
+        results[w] = {"samples": x_gen, "grid_path": grid_path}
+        if not chief:
+            continue
         save_samples(x_gen, grid_path, nrow=n_samples_per_class, denorm=denorm)             # :1040-1043
         for i in range(len(x_gen)):                                                        # :1045-1055 (file naming as the reference)
             name = class_names[(i // n_samples_per_class) % n_classes]
@@ -306,7 +388,7 @@ def gen_samples(ckpt_path, n_samples_per_class=Cfg.SAMPLES_PER_CLASS, guide_scal
             print(f"Image quality metrics (w={w}): " + ", ".join(f"{m.upper()} {v:.4f}" for m, v in quality[w].items()))
         results[w] = {"samples": x_gen, "grid_path": grid_path}
         print(f"guide scale {w}: wrote {grid_path}")
-    if eval_quality and quality:                                                           # :1075-1093
+    if chief and eval_quality and quality:                                                 # :1075-1093
         with open(os.path.join(samples_dir, "quality_metrics.json"), "w") as f:
             json.dump(_jsonable(quality), f, indent=2)
     return results
@@ -328,11 +410,22 @@ def main(argv=None):
     ap.add_argument("--batch_size", type=int, default=None)
     ap.add_argument("--dtype", choices=["float32", "bfloat16", "float16"], default=None)
     ap.add_argument("--bottleneck_k", type=int, default=None)
+    ap.add_argument("--gpus", type=int, default=None, help="start this many ranks (one process per GPU, RCCL data parallel); the same as "
+                                                           "running the script under torch.distributed.run --nproc-per-node N")
+    ap.add_argument("--no_plan", action="store_true", help="issue every training step eagerly (default: a fixed-shape step is captured once "
+                                                           "and replayed as a launch plan)")
     ap.add_argument("--data_root", default=None, help="dataset in the reference's layout (images/<class>/*.jpg + annotations/*.xml); "
                                                       "default: synthetic tensors")
     ap.add_argument("--convert_supervisely", nargs=2, metavar=("SPLIT_DIR", "DST_ROOT"), default=None,
                     help="lay a DatasetNinja / Supervisely split (img/ + ann/*.json, e.g. the bundled road-damage set) out as --data_root and exit")
     a = ap.parse_args(argv)
+    if a.gpus and a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # be the launcher: this process has made no GPU call; the children are this script, one rank per GPU
+        import sys
+        rest = list(sys.argv[1:] if argv is None else argv)
+        i = rest.index("--gpus")
+        del rest[i:i + 2]
+        raise SystemExit(parallel.launch_ranks(__file__, rest, a.gpus))
     if a.convert_supervisely:
         from diffusionmodel_amd.data import convert_supervisely
         print(f"wrote {convert_supervisely(*a.convert_supervisely)} images under {a.convert_supervisely[1]}")
@@ -342,7 +435,8 @@ def main(argv=None):
         if val is not None:
             setattr(Cfg, name, val)
     if a.mode == "train":
-        train_model(max_epochs=a.epochs, data_root=a.data_root)
+        kw = {"use_plan": False} if a.no_plan else {}
+        train_model(max_epochs=a.epochs, data_root=a.data_root, **kw)
     else:
         if not a.ckpt:
             ap.error("--mode generate needs --ckpt/--checkpoint")

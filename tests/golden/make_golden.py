@@ -280,6 +280,7 @@ def main():
     gen_bf16_autocast(R, lp=torch.float16, fname="fp16_autocast.npz")
     gen_train3(R)
     gen_train3(R, autocast=True)
+    gen_f128_b2(R)
     # key schema of the full-size nets (shapes only; no tensors are instantiated for the big ones)
     SCHEMA["ddpm_keys_F32_k4"] = [(k, list(v.shape)) for k, v in
                                   R.DDPM(make_ref_unet(R, 32, 4, 4), (1e-4, 0.02), 1000, "cpu").state_dict().items()]
@@ -532,8 +533,65 @@ def gen_train3(R, S=64, k=4, nf=32, ncls=4, B=2, n_T=1000, accum=2, n_opt=3, lr=
     print("train3 losses", res["losses"], "grad norms", res["grad_norms"])
 
 
+def gen_f128_b2(R, S=64, k=4, nf=128, ncls=4, B=2):
+    """The REFERENCE at the benchmark's width (BASELINE configs[1]: n_feat = 128, 64x64, k = 4), B = 2 -> f128_b2.npz: eps in
+    float64, float32 and under torch.autocast("cpu", bfloat16), eval and train; the probe loss; per-child gradient norms (fp64) and
+    the autocast run's norm / cosine against fp64.  Pins the HIP path AT THE BENCHMARK WIDTH to the reference itself (ADVICE r02:
+    until now F = 128 was held to the oracle only)."""
+    tag = "f128_b2"
+    net = make_ref_unet(R, nf, ncls, k)
+    load_synth(net)
+    init = {kk: v.clone() for kk, v in net.state_dict().items()}
+    x = synth.synth_input(tag + ".x", (B, 3, S, S))
+    c = torch.tensor([(3 * i + 1) % ncls for i in range(B)])
+    t = torch.tensor([(0.37 + 0.41 * i) % 1.0 for i in range(B)])
+    mk = torch.tensor([float((i + 1) % 2) for i in range(B)])
+    probe = synth.synth_input(tag + ".probe", (B, 3, S, S))
+    out = {"c": c.numpy(), "t": t.numpy(), "ctx_mask": mk.numpy()}
+    for train in (False, True):
+        mode = "train" if train else "eval"
+        net.load_state_dict(init)
+        net.double()
+        net.train(train)
+        net.zero_grad()
+        e64 = net(x.double(), c, t.double(), mk.double())
+        l64 = (e64 * probe.double()).mean()
+        l64.backward()
+        g64 = _per_child_grads(net)
+        net.float()
+        net.load_state_dict(init)
+        net.train(train)
+        net.zero_grad()
+        with torch.no_grad():
+            e32 = net(x, c, t, mk)
+        net.load_state_dict(init)
+        net.train(train)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            e16 = net(x, c, t, mk)
+            l16 = (e16.float() * probe).mean()
+        l16.backward()
+        g16 = _per_child_grads(net)
+        e16 = e16.detach().float()
+        out[f"{mode}.eps64"] = e64.detach().numpy()
+        out[f"{mode}.eps32_maxabs_vs_64"] = np.float64((e32.double() - e64.detach()).abs().max().item())
+        out[f"{mode}.mse_bf16_vs_64"] = np.float64(((e16.double() - e64.detach()) ** 2).mean().item())
+        out[f"{mode}.maxabs_bf16_vs_64"] = np.float64((e16.double() - e64.detach()).abs().max().item())
+        out[f"{mode}.power64"] = np.float64((e64.detach() ** 2).mean().item())
+        out[f"{mode}.loss64"] = np.float64(l64.item())
+        out[f"{mode}.loss_bf16"] = np.float64(l16.item())
+        for cn in g64:
+            out[f"{mode}.gn64.{cn}"] = np.float64(g64[cn].norm().item())
+            out[f"{mode}.gn_bf16.{cn}"] = np.float64(g16[cn].norm().item())
+            out[f"{mode}.cos_bf16.{cn}"] = np.float64(_cos(g16[cn], g64[cn]))
+        print("f128_b2", mode, "fp32 max|e32-e64|", out[f"{mode}.eps32_maxabs_vs_64"], "autocast mse", out[f"{mode}.mse_bf16_vs_64"],
+              "power", out[f"{mode}.power64"], "loss", l64.item(), l16.item())
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **out)
+
+
 if __name__ == "__main__":
-    if os.environ.get("DM_GOLDEN_ONLY") == "metrics":
+    if os.environ.get("DM_GOLDEN_ONLY") == "r03":          # the round-3 addition only
+        gen_f128_b2(_refload.load("new_scripy"))
+    elif os.environ.get("DM_GOLDEN_ONLY") == "metrics":
         gen_metrics_and_masks(_refload.load("new_scripy"))
     elif os.environ.get("DM_GOLDEN_ONLY") == "r02":        # the round-2 additions only (schema.json gets the new key merged in)
         R_ = _refload.load("new_scripy")

@@ -226,6 +226,82 @@ def f128_case(B=8, S=64, F=128):
     return out
 
 
+def f128_b2_case(dtype, modes=("eval", "train")):
+    """The benchmark's width against the REFERENCE ITSELF: tests/golden/f128_b2.npz (make_golden.py:gen_f128_b2 — the imported
+    reference at n_feat = 128, 64x64, k = 4, B = 2 in float64 / float32 / autocast(bfloat16)).  eps against the float64 run, the
+    probe loss, per-child gradient NORMS (the 106 M-element gradient vectors are not stored) against the float64 norms."""
+    import diffusionmodel_amd as D
+    tag, B, S, F = "f128_b2", 2, 64, 128
+    g = npz(tag)
+    ls = _loss_scale(dtype)
+    spec = O.context_unet_spec(3, F, 4, 4)
+    sd = synth.synth_state(spec)
+    x = si(tag + ".x", (B, 3, S, S))
+    c, t, mk = torch.tensor(g["c"]), torch.tensor(g["t"]), torch.tensor(g["ctx_mask"])
+    probe = si(tag + ".probe", (B, 3, S, S))
+    out = {}
+    for mode in modes:
+        net = D.ContextUnet(3, F, 4, bottleneck_k=4, dtype=dtype)
+        net.load_state_dict(sd, strict=True)
+        net = net.to(DEV)
+        net.train(mode == "train")
+        eps = net(x.to(DEV), c.to(DEV), t.to(DEV), mk.to(DEV))
+        loss = (eps * probe.to(DEV)).mean()
+        (loss * ls).backward()
+        e = eps.detach().cpu().double().numpy()
+        e64 = g[f"{mode}.eps64"]
+        norms = {cn: float(np.linalg.norm(v)) / ls for cn, v in child_grad_vectors(net).items()}
+        out[mode] = {
+            "eps_mse_vs_ref64": float(((e - e64) ** 2).mean()), "eps_maxabs_vs_ref64": float(np.abs(e - e64).max()),
+            "signal_power": float(g[f"{mode}.power64"]), "ref_fp32_maxabs": float(g[f"{mode}.eps32_maxabs_vs_64"]),
+            "ref_autocast_bf16_mse": float(g[f"{mode}.mse_bf16_vs_64"]), "ref_autocast_bf16_maxabs": float(g[f"{mode}.maxabs_bf16_vs_64"]),
+            "loss": float(loss.item()), "loss_ref64": float(g[f"{mode}.loss64"]), "loss_ref_autocast_bf16": float(g[f"{mode}.loss_bf16"]),
+            "probe_power": float((probe ** 2).mean()), "n_elements": int(probe.numel()),
+            "grad_norm_rel_err": {cn: norms[cn] / float(g[f"{mode}.gn64.{cn}"]) - 1.0 for cn in norms
+                                  if cn != "local_enhance" and float(g[f"{mode}.gn64.{cn}"]) > 0},
+            "ref_autocast_grad_norm_rel_err": {cn: float(g[f"{mode}.gn_bf16.{cn}"] / g[f"{mode}.gn64.{cn}"] - 1.0) for cn in norms
+                                               if cn != "local_enhance" and float(g[f"{mode}.gn64.{cn}"]) > 0},
+            "ref_autocast_one_minus_cos": {cn: float(1.0 - g[f"{mode}.cos_bf16.{cn}"]) for cn in norms if f"{mode}.cos_bf16.{cn}" in g.files},
+        }
+        del net
+    return out
+
+
+def cfg2_full_size_case(B=64, S=64, F=128):
+    """BASELINE configs[1] at its stated size (64x64, n_feat = 128, k = 4, B = 64, bf16), train mode, forward only: eps of the HIP
+    path and the DDPM.forward loss (draws injected) against the float32 oracle on the same weights; yardstick = the oracle under
+    torch.autocast("cpu", bfloat16).  Forward only so that the CPU side stays at a few seconds on the box's 16 threads."""
+    import diffusionmodel_amd as D
+    torch.manual_seed(4321)
+    net = D.ContextUnet(3, F, 4, bottleneck_k=4, dtype=torch.bfloat16)
+    sd = {k: v.detach().clone().cpu() for k, v in net.state_dict().items()}
+    ddpm = D.DDPM(net, (1e-4, 0.02), 1000, DEV, drop_prob=0.1)
+    ddpm.train()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, 3, S, S, generator=g).clamp_(-1, 1)
+    c = torch.randint(0, 4, (B,), generator=g)
+    ts = torch.randint(1, 1001, (B,), generator=g)
+    keep = (torch.rand(B, generator=g) > 0.1).float()
+    noise = torch.randn(B, 3, S, S, generator=g)
+    am = synth.synth_attn_mask(B, S)
+    t = ts.float() / 1000
+    with torch.no_grad():
+        eps = ddpm.nn_model(x.to(DEV), c.to(DEV), t.to(DEV), keep.to(DEV)).cpu().double().numpy()
+        ddpm.load_state_dict({**{"nn_model." + k: v for k, v in sd.items()}, **{k: getattr(ddpm, k) for k in D.SCHEDULE_KEYS}})
+        loss = float(ddpm(x.to(DEV), c.to(DEV), am.to(DEV), ts=ts.to(DEV), noise=noise.to(DEV), ctx_mask=keep.to(DEV)))
+    P = {k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        e32 = O.context_unet(P, x, c, t, keep, True).double().numpy()
+        P = {k: v.clone() for k, v in sd.items()}
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            e16 = O.context_unet(P, x, c, t, keep, True).float().double().numpy()
+        PD = {"nn_model." + k: v.clone() for k, v in sd.items()}
+        l32 = float(O.ddpm_loss(PD, O.ddpm_schedules(1e-4, 0.02, 1000), 1000, x, c, am, ts, noise, keep, True))
+    return {"eps_mse_vs_oracle32": float(((eps - e32) ** 2).mean()), "oracle_autocast_bf16_mse": float(((e16 - e32) ** 2).mean()),
+            "eps_maxabs_vs_oracle32": float(np.abs(eps - e32).max()), "oracle_autocast_bf16_maxabs": float(np.abs(e16 - e32).max()),
+            "signal_power": float((e32 ** 2).mean()), "loss": loss, "loss_oracle32": l32, "B": B}
+
+
 def train3_case(dtype):
     """Three optimiser steps (accumulation 2, clip 1.0, AdamW lr 1e-3 wd 1e-2) through the product path — DDPM.forward / ACCUM,
     backward, FusedAdamW.step — on the draws of tests/golden/train3.npz (the reference's loop on the CPU, fp32)."""

@@ -173,7 +173,9 @@ def test_context_unet_vs_reference_fixture(tag, S, k):
         e = eps.detach().cpu().numpy()
         err32, err64 = maxerr(e, g[f"{mode}.eps"]), maxerr(e, g[f"{mode}.eps64"])
         print(f"{tag} {mode}: max|eps - ref32| = {err32:.2e}, max|eps - ref64| = {err64:.2e}")
-        assert err64 < (3e-4 if train else 1e-4)
+        # north star: 1e-4 in fp32 mode.  64x64 train mode measures 3.9e-5 .. 4.6e-5 (the reference's own fp32-vs-fp64 noise in train mode
+        # at B = 2 is 2.3e-5); 128x128 train mode (4x the pixels behind every BatchNorm statistic of B = 2) keeps a stated 3e-4
+        assert err64 < (1e-4 if (not train or S == 64) else 3e-4)
         probe = si(tag + ".probe", tuple(eps.shape)).to(DEV)
         loss = (eps * probe).mean()
         loss.backward()
@@ -467,6 +469,79 @@ def test_overlapped_gradient_reducer_two_ranks_on_one_gpu():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "step 2" in r.stdout and "4/4" in r.stdout, r.stdout[-1500:]
     assert "planned DP:" in r.stdout, r.stdout[-1500:]               # the plan-replayed data-parallel step ran and agreed with the eager one
+
+
+def test_dp_product_configuration_one_process_nccl_side_stream_load():
+    """ONE process, nccl (RCCL) world size 1, the default 156-KiB-LDS kernels, OverlappedGradReducer in eager
+    and launch-plan mode, with a streaming load on the reducer's side stream while the backward pass runs (tests/dp_nccl1_sidestream.py):
+    the reduced flat gradient equals the no-reducer run of the same seeded pass to the fp32-atomics band.
+    (The child runs with DM_DEVICE_GUARD=0: this pytest process holds the device claim but is idle while it waits.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DM_DEVICE_GUARD="0", MASTER_PORT=str(29500 + os.getpid() % 200))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "dp_nccl1_sidestream.py")], capture_output=True, text=True, timeout=900,
+                       cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "dp_nccl1_sidestream OK" in r.stdout and "eager rep 5" in r.stdout, r.stdout[-2000:]
+
+
+def test_shared_device_guard_selects_the_small_kernels_on_the_device():
+    """after guard_shared_device / the per-process guard engage, the library really is on conv / wgrad variant 2 and a
+    3x3 convolution then runs on a <= 64-KiB kernel (dm_last_conv_path != halo); restored afterwards."""
+    from diffusionmodel_amd import _lib as L, ops as o
+    lib = L.load()
+    saved = dict(L._guard), L.LOCK_DIR
+    import tempfile
+    try:
+        x = torch.randn(4, 32, 32, 64, device=DEV).bfloat16()
+        w = torch.nn.Parameter(torch.randn(64, 64, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last))
+
+        class H:
+            weight, bias = w, None
+        sp = o.ConvSpec(3, 3, 1, 1)
+        with torch.no_grad():
+            y_big = o.conv_bn_act(x, None, H, None, sp)
+        assert lib.dm_last_conv_path() == 1                                       # the halo-resident kernel (156 KiB of LDS)
+        with tempfile.TemporaryDirectory() as td:
+            L._guard.update(fd=None, path=None, shared=False, checked=0)
+            L.LOCK_DIR = td
+            assert L.device_guard(identity="dup") is False
+            import fcntl
+            fd2 = os.open(L._guard["path"], os.O_RDWR)                            # "another process" on the same device
+            fcntl.flock(fd2, fcntl.LOCK_SH)
+            assert L.device_guard(recheck=True) is True
+            os.close(fd2)
+            assert lib.dm_get_conv_variant() == 2
+            with torch.no_grad():
+                y_small = o.conv_bn_act(x, None, H, None, sp)
+            assert lib.dm_last_conv_path() != 1
+            assert torch.allclose(y_small.float(), y_big.float(), rtol=2e-2, atol=2e-2)
+    finally:
+        if L._guard["fd"] is not None:
+            os.close(L._guard["fd"])
+        L._guard.clear()
+        L._guard.update(saved[0])
+        L.LOCK_DIR = saved[1]
+        lib.dm_set_conv_variant(L.DEFAULT_CONV_VARIANT)
+        lib.dm_set_wgrad_variant(3)
+
+
+def test_driver_engine_two_ranks_reproduce_the_reference_accumulation():
+    """Row X2: the engine new_scripy.train_model drives (diffusionmodel_amd/train.py), as two data-parallel ranks (gloo, one GPU),
+    reproduces the reference's single-process ACCUM_STEPS = 2 trajectory of tests/golden/train3.npz (new_scripy.py:777-803) within
+    the fp32 bars of the single-process test: rank == micro-batch of the accumulation group."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29300 + os.getpid() % 200
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tests", "dp_train3_ranks.py")],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "dp_train3 OK" in r.stdout, r.stdout[-1500:]
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 0.25)])

@@ -233,6 +233,87 @@ def test_gloo_overlapped_reducer_equals_plain_sum(tmp_path):
     assert torch.allclose(got0, loc0 + loc1, rtol=0, atol=1e-6)
 
 
+def _idle_worker(rank, world, port, out_dir):
+    """Steps 0-1: both ranks run a backward pass (observation, overlapped).  Step 2: rank 1 has no micro-batch (short tail of the
+    epoch) and joins through finish(idle=True) — it must issue the bucket collectives in the order rank 0's overlapped backward
+    issues them (the buckets differ in size: a wrong order fails or mis-sums) and the packed small-gradient reduce with the same length."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from diffusionmodel_amd import ops
+    parallel.init_from_env("gloo")
+    layout = [(37, True, True), (5, False, False), (1000, True, True), (8, False, False), (260, True, False), (513, True, True),
+              (3, False, False), (2048, True, True), (64, False, False), (700, True, True), (16, True, False)]
+    opt = _FakeOpt([(n, m) for n, m, _ in layout])
+    notifies = [nt for _, _, nt in layout]
+    red = parallel.OverlappedGradReducer(opt, n_buckets=3)
+    g = torch.Generator().manual_seed(200 + rank)
+    if rank == 1:
+        with pytest.raises(parallel.DmError):
+            red.begin()
+            red.finish(idle=True)                              # nothing learned yet: refused, not guessed
+    local = torch.zeros_like(opt.flat_g)
+    orders = []
+    for step in range(3):
+        opt.flat_g.zero_()
+        local.zero_()
+        red.begin()
+        idle = step == 2 and rank == 1
+        if not idle:
+            for (p, off, n), nt in reversed(list(zip(opt._slots, notifies))):
+                v = torch.randn(n, generator=g)
+                local[off:off + n] = v
+                if nt:
+                    opt.flat_g[off:off + n] = v
+                    ops.ON_WGRAD(p)
+                else:
+                    p.grad = v
+        red.finish(idle=idle)
+        orders.append(list(red._order))
+    torch.save((opt.flat_g.clone(), local.clone(), orders), os.path.join(out_dir, f"idle_{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_idle_rank_joins_the_tail_group(tmp_path):
+    import torch.multiprocessing as mp
+    world, port = 2, 33000 + os.getpid() % 2000
+    mp.spawn(_idle_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got0, loc0, ord0 = torch.load(os.path.join(str(tmp_path), "idle_0.pt"))
+    got1, loc1, ord1 = torch.load(os.path.join(str(tmp_path), "idle_1.pt"))
+    assert torch.equal(got0, got1) and float(loc1.abs().sum()) == 0.0
+    assert torch.allclose(got0, loc0, rtol=0, atol=1e-6)       # the idle rank contributed zeros
+    assert ord0[2] == ord1[2] and ord0[1] == ord1[2] and ord0[0] != ord0[1]     # idle order == overlapped order, not index order
+
+
+def test_epoch_partition_over_ranks_and_group_sizes():
+    """diffusionmodel_amd/train.py host logic: micro-batch m -> rank m % world; every rank walks the same number of slots; the ranks'
+    batches are a partition of ONE permutation per epoch; group sizes for ACCUM_STEPS vs world (new_scripy.py:786, 795)."""
+    from diffusionmodel_amd.train import StridedBatchSampler, group_size, rank_batches
+    assert group_size(4, 1) == (4, 4) and group_size(4, 4) == (4, 1) and group_size(4, 8) == (8, 1) and group_size(4, 2) == (4, 2)
+    assert group_size(3, 2) == (4, 2) and group_size(1, 1) == (1, 1)
+    assert rank_batches(5, 0, 2) == ([0, 2, 4], 3) and rank_batches(5, 1, 2) == ([1, 3, None], 3)
+    n, bs, world = 18, 4, 2
+    ss = [StridedBatchSampler(n, bs, r, world, shuffle=True, seed=5) for r in range(world)]
+    single = StridedBatchSampler(n, bs, 0, 1, shuffle=True, seed=5)
+    for ep in (0, 1):
+        for s_ in ss + [single]:
+            s_.set_epoch(ep)
+        per_rank = [list(s_) for s_ in ss]
+        whole = list(single)
+        assert [len(b) for b in whole] == [4, 4, 4, 4, 2]
+        inter = []
+        for m in range(single.n_batches):
+            inter.append(per_rank[m % world][m // world])
+        assert inter == whole                                   # rank r holds micro-batches r, r + world, ... of the same permutation
+        assert sorted(i for b in whole for i in b) == list(range(n))
+    assert list(StridedBatchSampler(n, bs, 0, 1, shuffle=True, seed=5)) != whole or True
+    e0 = StridedBatchSampler(n, bs, 0, 1, shuffle=True, seed=5)
+    e1 = StridedBatchSampler(n, bs, 0, 1, shuffle=True, seed=5)
+    e1.set_epoch(1)
+    assert list(e0) != list(e1)                                 # a new permutation every epoch
+    assert ss[0].slots == ss[1].slots == 3 and len(ss[0]) == 3 and len(ss[1]) == 2
+    assert list(StridedBatchSampler(6, 4, 0, 1, shuffle=False)) == [[0, 1, 2, 3], [4, 5]]
+
+
 # ---- sharded sampling: slices of the class-cycled batch, one all-gather, rank order ------------------------------------
 class _StubSampler:
     """Stands in for DDPM.sample on the CPU: encodes (global sample index, class) in the image it returns."""
@@ -313,6 +394,60 @@ def test_gloo_shared_device_guard(tmp_path, same):
     for rank in range(2):
         got = open(os.path.join(str(tmp_path), f"guard_{int(same)}_{rank}.txt")).read().split()
         assert got == ([ "1", "1"] if same else ["0", "0"])
+
+
+def _proc_guard_worker(lock_dir, out):
+    """A second PROCESS (not a rank of anybody's job) that uses the same physical GPU."""
+    os.environ["DM_LOCK_DIR"] = lock_dir
+    sys.path.insert(0, ROOT)
+    from diffusionmodel_amd import _lib as L
+    L.LOCK_DIR = lock_dir
+    first = L.device_guard(identity="gpu-under-test")
+    with open(out, "w") as f:
+        f.write(f"{int(first)} {L.load().dm_get_conv_variant()}")
+
+
+def test_process_level_device_guard(tmp_path, capfd):
+    """two INDEPENDENT processes on one GPU (train next to generate, two pytest workers) must not both run the
+    > 64-KiB-LDS kernels.  Every process holds a shared flock per physical device; a newcomer, and the first process at its next
+    re-check (FusedAdamW.step / GraphedTrainStep / DDPM.sample), switch themselves to conv / wgrad variant 2 and say so."""
+    import multiprocessing as mp
+    from diffusionmodel_amd import _lib as L
+    lib = L.load()
+    saved = dict(L._guard), L.LOCK_DIR
+    try:
+        L._guard.update(fd=None, path=None, shared=False, checked=0)
+        L.LOCK_DIR = str(tmp_path)
+        assert L.device_guard(identity="gpu-under-test") is False and lib.dm_get_conv_variant() == L.DEFAULT_CONV_VARIANT
+        assert L.device_guard(recheck=True) is False and L._guard["checked"] == 2          # alone: stays on the full-size kernels
+        assert L.device_guard(identity="another-gpu") is False                             # (the claim is per device; the first one stands)
+        ctx = mp.get_context("spawn")
+        out = str(tmp_path / "second.txt")
+        p = ctx.Process(target=_proc_guard_worker, args=(str(tmp_path), out))
+        p.start()
+        p.join(120)
+        assert p.exitcode == 0
+        assert open(out).read().split() == ["1", "2"]                                      # the newcomer saw us and took the small kernels
+        # it has exited: we are alone again, nothing changes for us
+        assert L.device_guard(recheck=True) is False
+        # a process that arrives and STAYS (an independent open file description holding the shared lock, as another process would)
+        import fcntl
+        fd2 = os.open(L._guard["path"], os.O_RDWR)
+        fcntl.flock(fd2, fcntl.LOCK_SH)
+        assert L.device_guard(recheck=True) is True and L.device_is_shared()
+        assert lib.dm_get_conv_variant() == 2
+        err = capfd.readouterr().err
+        assert "<= 64-KiB-LDS kernel variants" in err and "started using this GPU" in err
+        os.close(fd2)
+        assert L.device_guard(recheck=True) is True                                        # sticky: captured work may still hold the big kernels
+    finally:
+        if L._guard["fd"] is not None:
+            os.close(L._guard["fd"])
+        L._guard.clear()
+        L._guard.update(saved[0])
+        L.LOCK_DIR = saved[1]
+        lib.dm_set_conv_variant(L.DEFAULT_CONV_VARIANT)
+        lib.dm_set_wgrad_variant(3)
 
 
 def test_adamw_state_dict_schema_fixture_matches_torch():
