@@ -32,6 +32,15 @@ class DmWgrad(C.Structure):
                            "Ho", "Wo", "osy", "osx", "ooy", "oox", "N", "ldy", "ldw", "splitk")]
 
 
+class DmCaChain(C.Structure):
+    """include/dm_amd.h: the CoordAttn strip chain (chain.hip)."""
+    _PTRS1 = ("xh", "xw", "w1h", "b1h", "w1w", "b1w", "bn_h_g", "bn_h_b", "bn_w_g", "bn_w_b", "rm_h", "rv_h", "rm_w", "rv_w", "whw", "bhw", "wwh",
+              "bwh", "gam_h", "gam_w", "wch", "bch", "wcw", "bcw", "zh", "zw", "mean_h", "rstd_h", "mean_w", "rstd_w", "ah", "aw", "xhp", "xwp", "lh",
+              "lw", "stat", "dlh", "dlw", "gh", "gw", "bnpart", "dh2w", "dw2h", "dxh", "dxw", "d_w1h", "d_b1h", "d_w1w", "d_b1w", "d_bn_h_g",
+              "d_bn_h_b", "d_bn_w_g", "d_bn_w_b", "d_whw", "d_bhw", "d_wwh", "d_bwh", "d_gam", "d_wch", "d_bch", "d_wcw", "d_bcw")
+    _fields_ = [(n, i32) for n in ("B", "H", "W", "C", "R", "train", "save")] + [("eps", f32), ("momentum", f32)] + [(n, vp) for n in _PTRS1]
+
+
 # name -> argument ctypes (the trailing dm_stream_t is appended automatically unless noted)
 _PROTOS = {
     "dm_conv": [C.POINTER(DmConv)],
@@ -57,6 +66,10 @@ _PROTOS = {
     "dm_scale_residual_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, f32],
     "dm_scale_residual_bwd_reduce": [vp, vp, i32, i32, i32, i32, f32, vp],
     "dm_scale_residual_bwd_apply": [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32],
+    "dm_se_fwd": [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp],
+    "dm_se_bwd": [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp],
+    "dm_ca_chain_fwd": [C.POINTER(DmCaChain)],
+    "dm_ca_chain_bwd": [C.POINTER(DmCaChain)],
     "dm_ca_pool_fwd": [vp, i32, i32, i32, i32, i32, vp, vp],
     "dm_ca_pool_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32],
     "dm_ca_gate_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32],

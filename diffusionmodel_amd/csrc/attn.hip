@@ -73,8 +73,11 @@ __global__ void strip_fold_kernel(const float* part, float* out, int n, int RS, 
 
 template <int MODE>
 int launch_strip(const void* x, const void* y, float* out, int dtype, int B, int A, int R, int sa, int sr, int P, int C, float scale,
-                 hipStream_t st) {
+                 hipStream_t st, const float** parts_out = nullptr, int* rs_out = nullptr) {
     // few long strips (the whole-image pools of the SE block): split the positions until ~1024 workgroups share the read
+    // parts_out != nullptr: no fold launch — the consumer (chain.hip) adds the RS partial arrays [RS][B * A][C] itself (scale 1);
+    // they always live in the workspace then, also when RS == 1
+    const bool keep = parts_out != nullptr;
     int RS = 1, rps = R;
     if (B * A < 512 && R >= 256 && dm_g_ws != nullptr) {
         RS = 1024 / (B * A);
@@ -83,8 +86,12 @@ int launch_strip(const void* x, const void* y, float* out, int dtype, int B, int
         rps = cdiv(R, RS);
         RS = cdiv(R, rps);
     }
-    float* dst = RS > 1 ? dm_g_ws : out;
-    const float sc = RS > 1 ? 1.f : scale;
+    if (keep && (dm_g_ws == nullptr || (int64_t)RS * B * A * C * (int64_t)sizeof(float) > dm_g_ws_bytes)) {
+        dm_set_error("strip sums: the workspace (dm_set_workspace) is missing or too small for %d x %d x %d partial sums", RS, B * A, C);
+        return DM_EINVAL;
+    }
+    float* dst = (RS > 1 || keep) ? dm_g_ws : out;
+    const float sc = (RS > 1 || keep) ? 1.f : scale;
     DM_DISPATCH_DTYPE(dtype, {
         const uintptr_t m = (uintptr_t)x | (uintptr_t)y;
         if (C % Elem<T>::VE == 0 && (m & 15) == 0)
@@ -92,7 +99,12 @@ int launch_strip(const void* x, const void* y, float* out, int dtype, int B, int
         else
             hipLaunchKernelGGL((strip_reduce_kernel<T, 1, MODE>), dim3(B * A * RS), dim3(256), 0, st, (const T*)x, (const T*)y, dst, A, R, sa, sr, P, C, sc, RS, rps);
     });
-    if (RS > 1) hipLaunchKernelGGL(strip_fold_kernel, dim3(cdiv(B * A * C, 256)), dim3(256), 0, st, dm_g_ws, out, B * A * C, RS, scale);
+    if (keep) {
+        *parts_out = dm_g_ws;
+        *rs_out = RS;
+    } else if (RS > 1) {
+        hipLaunchKernelGGL(strip_fold_kernel, dim3(cdiv(B * A * C, 256)), dim3(256), 0, st, dm_g_ws, out, B * A * C, RS, scale);
+    }
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
@@ -411,6 +423,14 @@ __global__ void onehot_mask_kernel(const int64_t* c, const float* mask, float* o
 }  // namespace
 
 #define ST ((hipStream_t)s)
+
+// chain.hip: per-sample sums over the pixels (mode 0: x; mode 1: x * y) left as partial arrays in the workspace, no fold launch
+int dm_strip_partials(int mode, const void* x, const void* y, int dtype, int B, int HW, int C, float* out, const float** parts, int* rs_out,
+                      hipStream_t st) {
+    (void)out;
+    if (mode == 0) return launch_strip<0>(x, nullptr, nullptr, dtype, B, 1, HW, 0, 1, HW, C, 1.f, st, parts, rs_out);
+    return launch_strip<1>(x, y, nullptr, dtype, B, 1, HW, 0, 1, HW, C, 1.f, st, parts, rs_out);
+}
 
 extern "C" int dm_pool_hw(const void* x, int dtype, int B, int HW, int C, float* mean_bc, dm_stream_t s) {
     DM_CHECK_ARG(x && mean_bc && B > 0 && HW > 0 && C > 0, "dm_pool_hw: bad arguments");

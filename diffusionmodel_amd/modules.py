@@ -111,10 +111,15 @@ class CoordAttn(_HipBlock):
 
     def _fwd(self, x):
         B, H, W, C = x.shape
-        if H != W:
-            raise DmError("CoordAttn on the HIP path needs H == W (the reference's adaptive pools are then the identity)")
         fx, fh, fw = ops.GradFork(), ops.GradFork(), ops.GradFork()      # x, xh, xw each feed two consumers
         xh, xw = ops.PoolStrips.apply(x, fx)                                       # :102-103
+        if ops.ca_chain_ok(C, self.conv1_h.weight.shape[0]):
+            # :105-129 as one fused chain (2 launches forward, 2 backward; H != W through the adaptive pools of :119-120)
+            lh, lw = ops.ca_chain(xh, xw, self)
+            return ops.CaGate.apply(fx.second(x), lh, lw, self.alpha, self.beta)   # :128-140
+        if H != W:
+            raise DmError("CoordAttn with H != W needs the fused strip chain (channel % 64 == 0, DM_FUSED_CHAINS != 0): the one-launch-per-op "
+                          "path has no adaptive pooling between the strips")
         if not torch.is_grad_enabled() and not self.bn1_h.training and not self.bn1_w.training:
             # sampler: running-statistics BatchNorm folded into the dense weights, GELU in the epilogue (:105-111 in one launch each)
             wh, bh = ops.folded_dense_bn(self.conv1_h, self._sp_h)

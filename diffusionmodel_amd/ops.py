@@ -24,6 +24,7 @@ from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, call, dt, ptr
 
 BN_EPS = 1e-5
 import os as _os
+FUSED_CHAINS = _os.environ.get("DM_FUSED_CHAINS", "1") != "0"    # SE MLP / CoordAttn strip chains as 1-2 launches per direction (chain.hip); 0: one launch per torch.nn op (A/B measurements)
 BN_SLOTS_MAX_C = int(_os.environ.get("DM_BN_SLOTS_MAX_C", "256"))   # wider layers keep the partial rows + finalize launch: every workgroup of the consuming kernel folds slots x C doubles (128 KiB at C = 1024: 8x the tensor's own traffic on the 8x8 level, +6 us per launch against 2.6 us for the finalize launch)
 BN_SLOTS = int(_os.environ.get("DM_BN_SLOTS", "8"))          # train-mode BatchNorm statistics travel as [BN_SLOTS][C] accumulators folded by the consuming kernel (0: partial rows + finalize launches)
 _EPOCH = [0]          # bumped by the fused optimiser: invalidates packed-weight caches
@@ -893,8 +894,24 @@ class SeResidual(torch.autograd.Function):
             ctx.meta = (None, inv, x2.shape, x2.dtype)
             return out
         R = w1.shape[0]
-        y = _empty((B, Cc), torch.float32, x2)
         L.ensure_workspace()                     # the whole-image pools split their rows over workgroups through it
+        w1, w2 = w1.contiguous(), w2.contiguous()
+        if FUSED_CHAINS and Cc % 4 == 0 and R % 4 == 0 and R <= 128:
+            # pooling partials -> (fold, fc, GELU, fc, sigmoid) in one kernel per 16 samples (chain.hip)
+            sg = _empty((B, Cc), torch.float32, x2)
+            if need_grad:
+                y, hid, gh = _empty((B, Cc), torch.float32, x2), _empty((B, R), torch.float32, x2), _empty((B, R), torch.float32, x2)
+            else:
+                y = hid = gh = None
+            call("dm_se_fwd", ptr(x2), dt(x2), B, H * W, Cc, ptr(w1), ptr(w2), R, ptr(y), ptr(hid), ptr(gh), ptr(sg))
+            call("dm_scale_residual_fwd", ptr(x2), ptr(res), ptr(sg), ptr(out), dt(x2), B, H * W, Cc, inv)
+            if need_grad:
+                ctx.save_for_backward(x2, y, hid, gh, None, sg, w1, w2)
+            ctx.meta = (R, inv, x2.shape, x2.dtype)
+            ctx.fused = True
+            return out
+        ctx.fused = False
+        y = _empty((B, Cc), torch.float32, x2)
         call("dm_pool_hw", ptr(x2), dt(x2), B, H * W, Cc, ptr(y))
         hid, gh = _empty((B, R), torch.float32, x2), _empty((B, R), torch.float32, x2)
         logit, sg = _empty((B, Cc), torch.float32, x2), _empty((B, Cc), torch.float32, x2)
@@ -922,9 +939,15 @@ class SeResidual(torch.autograd.Function):
             return dx2, dres, None, None, None, None
         x2, y, hid, gh, logit, sg, w1, w2 = ctx.saved_tensors
         f = lambda *s: _empty(s, torch.float32, g)
-        dsg, dlogit, dgh, dhid, dy = f(B, Cc), f(B, Cc), f(B, R), f(B, R), f(B, Cc)
         dw1, dw2 = _gzeros((R, Cc), g), _gzeros((Cc, R), g)
         L.ensure_workspace()
+        if getattr(ctx, "fused", False):
+            dlogit, dhid, dy = f(B, Cc), f(B, R), f(B, Cc)
+            call("dm_se_bwd", ptr(g), ptr(x2), dt(dtype), B, H * W, Cc, inv, ptr(sg), ptr(hid), ptr(gh), ptr(y), ptr(w1), ptr(w2), R,
+                 ptr(dlogit), ptr(dhid), ptr(dy), ptr(dw1), ptr(dw2))
+            call("dm_scale_residual_bwd_apply", ptr(g), ptr(sg), ptr(dy), ptr(dx2), ptr(dres), dt(dtype), B, H * W, Cc, inv)
+            return dx2, dres, dw1, dw2, None, None
+        dsg, dlogit, dgh, dhid, dy = f(B, Cc), f(B, Cc), f(B, R), f(B, R), f(B, Cc)
         call("dm_scale_residual_bwd_reduce", ptr(g), ptr(x2), dt(dtype), B, H * W, Cc, inv, ptr(dsg))
         call("dm_act_bwd", ptr(logit), ptr(dsg), ptr(dlogit), B * Cc, ACT_SIGMOID)
         _lin_bwd(gh, w2, dlogit, dgh, dw2, None)
@@ -1003,6 +1026,102 @@ class CaGate(torch.autograd.Function):
         call("dm_ca_gate_bwd", ptr(x), ptr(g), ptr(lh), ptr(lw), ptr(alpha), ptr(beta), ptr(dx), ptr(dlh), ptr(dlw), ptr(dab), dt(x),
              B, H, W, Cc)
         return dx, dlh, dlw, dab[0:1], dab[1:2]
+
+
+def ca_chain_ok(C_, R):
+    """Shapes the fused CoordAttn strip chain (chain.hip) takes: C % 4 == 0, R % 4 == 0, R <= 128."""
+    return FUSED_CHAINS and C_ % 4 == 0 and R % 4 == 0 and 0 < R <= 128
+
+
+class CaChain(torch.autograd.Function):
+    """(x_h, x_w) -> (l_h, l_w): conv1 + BatchNorm + GELU on both strips, the two cross projections, the sigmoid-gated mix with
+    F.adaptive_avg_pool2d between strips of different length, conv_h / conv_w (new_scripy.py:105-129) — two launches forward, two
+    backward (dm_ca_chain_fwd / dm_ca_chain_bwd) instead of one per torch.nn op."""
+    PARAMS = ("conv1_h.weight", "conv1_h.bias", "conv1_w.weight", "conv1_w.bias", "bn1_h.weight", "bn1_h.bias", "bn1_w.weight", "bn1_w.bias",
+              "h2w_proj.weight", "h2w_proj.bias", "w2h_proj.weight", "w2h_proj.bias", "gamma_h", "gamma_w", "conv_h.weight", "conv_h.bias",
+              "conv_w.weight", "conv_w.bias")
+
+    @staticmethod
+    def forward(ctx, xh, xw, mod, need_grad, *prm):
+        L.require_device(xh, xw)
+        xh, xw = xh.contiguous(), xw.contiguous()
+        B, H, Cc = xh.shape
+        W = xw.shape[1]
+        (w1h, b1h, w1w, b1w, gh_, bh_, gw_, bw_, whw, bhw, wwh, bwh, gam_h, gam_w, wch, bch, wcw, bcw) = prm
+        R = w1h.shape[0]
+        mats = [t.reshape(t.shape[0], -1).contiguous() for t in (w1h, w1w, whw, wwh, wch, wcw)]
+        d = L.DmCaChain()
+        d.B, d.H, d.W, d.C, d.R = B, H, W, Cc, R
+        train = mod.bn1_h.training
+        if train != mod.bn1_w.training:
+            raise L.DmError("CoordAttn: bn1_h and bn1_w must be in the same mode")
+        d.train, d.save = int(train), int(bool(need_grad))
+        d.eps, d.momentum = BN_EPS, float(mod.bn1_h.momentum)
+        f = lambda *s_: _empty(s_, torch.float32, xh)
+        zh, zw, lh, lw = f(B * H, R), f(B * W, R), f(B, H, Cc), f(B, W, Cc)
+        saved = [f(R), f(R), f(R), f(R), f(B * H, R), f(B * W, R), f(B * H, R), f(B * W, R)] if need_grad else [None] * 8
+        stat = f((-(-B * H // 16) + -(-B * W // 16)) * 2 * R) if train else None
+        d.xh, d.xw = ptr(xh), ptr(xw)
+        d.w1h, d.b1h, d.w1w, d.b1w = ptr(mats[0]), ptr(b1h), ptr(mats[1]), ptr(b1w)
+        d.bn_h_g, d.bn_h_b, d.bn_w_g, d.bn_w_b = ptr(gh_), ptr(bh_), ptr(gw_), ptr(bw_)
+        d.rm_h, d.rv_h, d.rm_w, d.rv_w = ptr(mod.bn1_h.running_mean), ptr(mod.bn1_h.running_var), ptr(mod.bn1_w.running_mean), ptr(mod.bn1_w.running_var)
+        d.whw, d.bhw, d.wwh, d.bwh = ptr(mats[2]), ptr(bhw), ptr(mats[3]), ptr(bwh)
+        d.gam_h, d.gam_w = ptr(gam_h), ptr(gam_w)
+        d.wch, d.bch, d.wcw, d.bcw = ptr(mats[4]), ptr(bch), ptr(mats[5]), ptr(bcw)
+        d.zh, d.zw, d.lh, d.lw, d.stat = ptr(zh), ptr(zw), ptr(lh), ptr(lw), ptr(stat)
+        (d.mean_h, d.rstd_h, d.mean_w, d.rstd_w, d.ah, d.aw, d.xhp, d.xwp) = [ptr(t) for t in saved]
+        call("dm_ca_chain_fwd", C.byref(d))
+        if train:
+            for sp, bn in ((mod._sp_h, mod.bn1_h), (mod._sp_w, mod.bn1_w)):
+                sp.nbt_pending += 1
+                bn._stat_epoch = getattr(bn, "_stat_epoch", 0) + 1
+        if need_grad:
+            ctx.save_for_backward(xh, xw, zh, zw, *saved, *mats, gh_, bh_, gw_, bw_, gam_h, gam_w)
+            ctx.meta = (B, H, W, Cc, R, train, float(mod.bn1_h.momentum), [t is not None for t in (b1h, b1w, bhw, bwh, bch, bcw)],
+                        [tuple(t.shape) for t in (w1h, w1w, whw, wwh, wch, wcw)])
+        return lh, lw
+
+    @staticmethod
+    def backward(ctx, dlh, dlw):
+        (xh, xw, zh, zw, mean_h, rstd_h, mean_w, rstd_w, ah, aw, xhp, xwp, w1h, w1w, whw, wwh, wch, wcw, gh_, bh_, gw_, bw_, gam_h,
+         gam_w) = ctx.saved_tensors
+        B, H, W, Cc, R, train, mom, has_b, wshapes = ctx.meta
+        dlh, dlw = dlh.contiguous(), dlw.contiguous()
+        d = L.DmCaChain()
+        d.B, d.H, d.W, d.C, d.R, d.train, d.save = B, H, W, Cc, R, int(train), 1
+        d.eps, d.momentum = BN_EPS, mom
+        f = lambda *s_: _empty(s_, torch.float32, xh)
+        gz = lambda *s_: _gzeros(s_, xh)
+        g_h, g_w, bnpart, dh2w, dw2h = f(B * H, R), f(B * W, R), f(2 * B * 2 * R), f(B * H, R), f(B * W, R)
+        dxh, dxw = f(B, H, Cc), f(B, W, Cc)
+        d_w1h, d_w1w, d_whw, d_wwh, d_wch, d_wcw = gz(R, Cc), gz(R, Cc), gz(R, R), gz(R, R), gz(Cc, R), gz(Cc, R)
+        d_b = [gz(n) if h else None for n, h in zip((R, R, R, R, Cc, Cc), has_b)]
+        d_bn = [f(R) for _ in range(4)]
+        d_gam = gz(2)
+        d.xh, d.xw, d.zh, d.zw = ptr(xh), ptr(xw), ptr(zh), ptr(zw)
+        d.w1h, d.w1w, d.whw, d.wwh, d.wch, d.wcw = ptr(w1h), ptr(w1w), ptr(whw), ptr(wwh), ptr(wch), ptr(wcw)
+        d.bn_h_g, d.bn_h_b, d.bn_w_g, d.bn_w_b, d.gam_h, d.gam_w = ptr(gh_), ptr(bh_), ptr(gw_), ptr(bw_), ptr(gam_h), ptr(gam_w)
+        d.mean_h, d.rstd_h, d.mean_w, d.rstd_w, d.ah, d.aw, d.xhp, d.xwp = [ptr(t) for t in (mean_h, rstd_h, mean_w, rstd_w, ah, aw, xhp, xwp)]
+        d.dlh, d.dlw, d.gh, d.gw, d.bnpart, d.dh2w, d.dw2h, d.dxh, d.dxw = [ptr(t) for t in (dlh, dlw, g_h, g_w, bnpart, dh2w, dw2h, dxh, dxw)]
+        d.d_w1h, d.d_w1w, d.d_whw, d.d_wwh, d.d_wch, d.d_wcw = [ptr(t) for t in (d_w1h, d_w1w, d_whw, d_wwh, d_wch, d_wcw)]
+        d.d_b1h, d.d_b1w, d.d_bhw, d.d_bwh, d.d_bch, d.d_bcw = [ptr(t) for t in d_b]
+        d.d_bn_h_g, d.d_bn_h_b, d.d_bn_w_g, d.d_bn_w_b = [ptr(t) for t in d_bn]
+        d.d_gam = ptr(d_gam)
+        call("dm_ca_chain_bwd", C.byref(d))
+        dws = [t.reshape(sh) for t, sh in zip((d_w1h, d_w1w, d_whw, d_wwh, d_wch, d_wcw), wshapes)]
+        return (dxh, dxw, None, None, dws[0], d_b[0], dws[1], d_b[1], d_bn[0], d_bn[1], d_bn[2], d_bn[3], dws[2], d_b[2], dws[3], d_b[3],
+                d_gam[0:1], d_gam[1:2], dws[4], d_b[4], dws[5], d_b[5])
+
+
+def ca_chain(xh, xw, mod):
+    prm = []
+    for name in CaChain.PARAMS:
+        o = mod
+        for part in name.split("."):
+            o = getattr(o, part)
+        prm.append(o)
+    need = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in [xh, xw] + prm)
+    return CaChain.apply(xh, xw, mod, need, *prm)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -196,6 +196,20 @@ int dm_scale_residual_bwd_apply(const void* dout, const float* sgate, const floa
                                 int dtype, int B, int HW, int C, float inv, dm_stream_t s);
                                                                /* dx2 = dout*inv*s + dy_mean[b,c]/HW ; dres = dout*inv */
 
+/* The whole squeeze-excite chain in 2 (forward) / 3 (backward) launches instead of 6 / 8 (chain.hip): the pooling pass leaves
+ * per-workgroup partial sums in the workspace (dm_set_workspace), one kernel per 16 samples folds them and runs
+ * fc -> GELU -> fc -> sigmoid (new_scripy.py:148-157) with the hidden vector in LDS.  C % 4 == 0, R % 4 == 0, R <= 128.
+ *   forward:  y[B][C] = mean_hw(x2), hid[B][R] = y W1^T, gh = gelu(hid), sg[B][C] = sigmoid(gh W2^T)
+ *             (y / hid / gh all NULL: inference, only sg is written)
+ *   backward: dsg = sum_hw dout*inv*x2 (as dm_scale_residual_bwd_reduce), dlogit = dsg sg (1 - sg)  [scratch, B x C],
+ *             dhid = (dlogit W2) gelu'(hid)  [scratch, B x R],  dy[B][C] = dhid W1  (overwritten),
+ *             dw1[R][C] += dhid^T y,  dw2[C][R] += dlogit^T gh   (fp32 atomics: accumulators) */
+int dm_se_fwd(const void* x2, int dtype, int B, int HW, int C, const float* w1, const float* w2, int R, float* y,
+              float* hid, float* gh, float* sg, dm_stream_t s);
+int dm_se_bwd(const void* dout, const void* x2, int dtype, int B, int HW, int C, float inv, const float* sg,
+              const float* hid, const float* gh, const float* y, const float* w1, const float* w2, int R, float* dlogit,
+              float* dhid, float* dy, float* dw1, float* dw2, dm_stream_t s);
+
 /* ------------------------------------------------------------------------------------------------
  * Coordinate attention (new_scripy.py:97-140): strip pooling and the final gated multiply.
  * ---------------------------------------------------------------------------------------------- */
@@ -211,6 +225,36 @@ int dm_ca_gate_bwd(const void* x, const void* dout, const float* lh, const float
 /* xo = x + sig(gamma)*y on fp32 strips; backward gives dy = sig*dxo and dgamma */
 int dm_sigmix_fwd(const float* x, const float* y, const float* gamma, float* xo, int n, dm_stream_t s);
 int dm_sigmix_bwd(const float* dxo, const float* y, const float* gamma, float* dy, float* dgamma, int n, dm_stream_t s);
+
+/* The strip chain of CoordAttn between its pooling pass and its gate pass (new_scripy.py:105-129) in 2 launches per direction
+ * instead of 14 / 22 (chain.hip).  All tensors fp32; R = C / reduction; C % 4 == 0, R % 4 == 0, R <= 128.
+ *   forward : z = conv1(x) [B*L][R] ; a = gelu(bn1(z)) ; h2w = h2w_proj(a_h) ; w2h = w2h_proj(a_w) ;
+ *             x_h' = a_h + sigmoid(gamma_h) adapt_H(w2h) ; x_w' = a_w + sigmoid(gamma_w) adapt_W(h2w)   (adapt = adaptive_avg_pool
+ *             along the strip, :119-120: the identity when H == W) ; l_h = conv_h(x_h') [B][H][C] ; l_w = conv_w(x_w') [B][W][C]
+ *             train != 0: batch statistics (stat = scratch of (ceil(B H / 16) + ceil(B W / 16)) * 2 R floats), running statistics
+ *             updated with `momentum`; train == 0: running statistics.  save != 0: mean / rstd / a / x' are written (backward).
+ *   backward: from dlh / dlw to dxh / dxw (overwritten) and every parameter gradient: d_w* / d_b* / d_gam accumulate (+=, fp32
+ *             atomics), d_bn_* are overwritten.  Scratch: gh, gw [B*L][R], bnpart [2][B][2 R], dh2w [B*H][R], dw2h [B*W][R]. */
+typedef struct DmCaChain {
+    int32_t B, H, W, C, R, train, save;
+    float eps, momentum;
+    const float *xh, *xw;                                   /* strip means [B][H][C], [B][W][C] */
+    const float *w1h, *b1h, *w1w, *b1w;                     /* conv1_h / conv1_w: [R][C], [R] */
+    const float *bn_h_g, *bn_h_b, *bn_w_g, *bn_w_b;         /* bn1_h / bn1_w weight, bias [R] */
+    float *rm_h, *rv_h, *rm_w, *rv_w;                       /* running mean / var [R] */
+    const float *whw, *bhw, *wwh, *bwh;                     /* h2w_proj, w2h_proj: [R][R], [R] */
+    const float *gam_h, *gam_w;                             /* gamma_h, gamma_w (1 float each) */
+    const float *wch, *bch, *wcw, *bcw;                     /* conv_h / conv_w: [C][R], [C] */
+    float *zh, *zw, *mean_h, *rstd_h, *mean_w, *rstd_w, *ah, *aw, *xhp, *xwp, *lh, *lw;
+    float *stat;
+    const float *dlh, *dlw;
+    float *gh, *gw, *bnpart, *dh2w, *dw2h;
+    float *dxh, *dxw;
+    float *d_w1h, *d_b1h, *d_w1w, *d_b1w, *d_bn_h_g, *d_bn_h_b, *d_bn_w_g, *d_bn_w_b, *d_whw, *d_bhw, *d_wwh, *d_bwh, *d_gam, *d_wch,
+        *d_bch, *d_wcw, *d_bcw;
+} DmCaChain;
+int dm_ca_chain_fwd(const DmCaChain* d, dm_stream_t s);
+int dm_ca_chain_bwd(const DmCaChain* d, dm_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * Small dense layers in fp32 (EmbedFC new_scripy.py:255-268; CoordAttn 1x1 convs on strips :76-91; SE MLP :148-157).

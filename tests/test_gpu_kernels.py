@@ -830,3 +830,123 @@ def test_pointwise_wgrad_kernel_exact_integers(dtype, B, C, N, H):
             assert torch.equal(conv.weight.grad.cpu(), wr.grad)
     finally:
         assert lib.dm_set_wgrad_pw(1, 384, 0) == 0
+
+
+# ---- fused attention chains (chain.hip): against the one-launch-per-op path AND torch on the CPU --------------------------------
+@pytest.mark.parametrize("B,C,HW,dtype", [(64, 128, 4096, torch.bfloat16), (5, 1024, 64, torch.bfloat16), (20, 1536, 16, torch.float32),
+                                          (2, 32, 256, torch.float32), (33, 256, 1024, torch.float16), (16, 2048, 64, torch.float32)])
+def test_fused_se_chain_matches_unfused_and_torch(B, C, HW, dtype):
+    """SeResidual = (res + x2 * sigmoid(W2 gelu(W1 mean_hw(x2)))) / 1.414 (new_scripy.py:143-158, 196-205): the fused chain
+    (dm_se_fwd / dm_se_bwd: pooling partials folded inside the MLP kernel, hidden vector in LDS) against the r02 path
+    (pool, fold, 2 dense, 2 activation launches) and against torch fp32 on the CPU — forward, dx2, dres, dW1, dW2."""
+    from diffusionmodel_amd import ops as o
+    torch.manual_seed(C + B)
+    R = C // 16
+    H = int(math.isqrt(HW))
+    W = HW // H
+    x2 = torch.randn(B, H, W, C).to(dtype)
+    res = torch.randn(B, H, W, C).to(dtype)
+    w1 = torch.randn(R, C) / math.sqrt(C)
+    w2 = torch.randn(C, R) / math.sqrt(R)
+    probe = torch.randn(B, H, W, C)
+    inv = 1.0 / 1.414
+
+    def run(fused):
+        o.FUSED_CHAINS = fused
+        a, b = x2.to(DEV).requires_grad_(True), res.to(DEV).requires_grad_(True)
+        p1, p2 = torch.nn.Parameter(w1.to(DEV)), torch.nn.Parameter(w2.to(DEV))
+        out = o.SeResidual.apply(a, b, p1, p2, inv, True)
+        (out.float() * probe.to(DEV)).sum().backward()
+        with torch.no_grad():
+            out_ng = o.SeResidual.apply(x2.to(DEV), res.to(DEV), p1, p2, inv, False)
+        return [t.detach().float().cpu() for t in (out, a.grad, b.grad, p1.grad, p2.grad, out_ng)]
+    try:
+        fu, un = run(True), run(False)
+    finally:
+        o.FUSED_CHAINS = True
+    # torch reference on the values the kernels see (the 16-bit inputs, fp32 math)
+    a, b = x2.float().requires_grad_(True), res.float().requires_grad_(True)
+    p1, p2 = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    y = a.mean(dim=(1, 2))
+    sg = torch.sigmoid(F.gelu(y @ p1.t()) @ p2.t())
+    out = (b + a * sg[:, None, None, :]) * inv
+    (out * probe).sum().backward()
+    ref = [out.detach(), a.grad, b.grad, p1.grad, p2.grad, out.detach()]
+    tol = 2e-5 if dtype == torch.float32 else 1.2e-2
+    for name, f_, u_, r_ in zip(("out", "dx2", "dres", "dW1", "dW2", "out(no grad)"), fu, un, ref):
+        scale = float(r_.abs().max()) + 1e-12
+        ef, eu = float((f_ - r_).abs().max()) / scale, float((u_ - r_).abs().max()) / scale
+        assert ef <= max(tol, 1.5 * eu), (name, ef, eu)
+        assert float((f_ - u_).abs().max()) / scale <= tol, (name, float((f_ - u_).abs().max()) / scale)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(4, 64, 8, 8), (8, 128, 32, 32), (16, 1024, 4, 4), (3, 128, 16, 24), (2, 2048, 8, 8), (5, 192, 6, 10),
+                                     (2, 64, 40, 17)])
+@pytest.mark.parametrize("train", [False, True])
+def test_fused_coordattn_chain_matches_the_oracle_and_the_unfused_path(B, C, H, W, train):
+    """CoordAttn (new_scripy.py:70-140) with the strip chain fused (dm_ca_chain_fwd / _bwd: conv1 + BatchNorm + GELU, the cross
+    projections, the gated mix with adaptive pooling between strips of different length, conv_h / conv_w) in fp32: output, input
+    gradient and every parameter gradient against the float64 oracle (which follows the reference line by line, adaptive pools
+    included: H != W is covered — VERDICT r02 missing #4) and, where the one-launch-per-op path exists (H == W), against it."""
+    import diffusionmodel_amd as D
+    from diffusionmodel_amd import ops as o
+    from oracle import unet_ref as O
+    torch.manual_seed(1000 + C + H)
+    mod = D.CoordAttn(C).to(DEV)
+    with torch.no_grad():
+        for n_, p_ in mod.named_parameters():
+            if p_.dim() == 1 and p_.numel() == 1:
+                p_.fill_(0.3 if "gamma" in n_ else -0.2)
+            elif "bn1" in n_:
+                p_.uniform_(0.5, 1.5) if n_.endswith("weight") else p_.uniform_(-0.2, 0.2)
+        for n_, b_ in mod.named_buffers():
+            if n_.endswith("running_mean"):
+                b_.normal_(0, 0.1)
+            elif n_.endswith("running_var"):
+                b_.uniform_(0.6, 1.4)
+    sd = {k: v.detach().clone().cpu() for k, v in mod.state_dict().items()}
+    x = torch.randn(B, C, H, W)
+    probe = torch.randn(B, C, H, W)
+
+    def run(fused):
+        o.FUSED_CHAINS = fused
+        mod.load_state_dict(sd)
+        mod.train(train)
+        mod.zero_grad()
+        xd = x.to(DEV).requires_grad_(True)
+        y = mod(xd)
+        (y * probe.to(DEV)).sum().backward()
+        out = {"y": y.detach().cpu(), "dx": xd.grad.cpu()}
+        out.update({"d." + n_: p_.grad.detach().cpu().reshape(-1) for n_, p_ in mod.named_parameters()})
+        out.update({"buf." + n_: b_.detach().cpu().float() for n_, b_ in mod.named_buffers() if "running" in n_})
+        with torch.no_grad():
+            mod.load_state_dict(sd)
+            mod.train(train)
+            out["y_nograd"] = mod(x.to(DEV)).cpu()
+        return out
+    try:
+        fu = run(True)
+        un = run(False) if H == W else None
+    finally:
+        o.FUSED_CHAINS = True
+    P = {"ca." + k: (v.double().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone().double() if v.is_floating_point() else v.clone())
+         for k, v in sd.items()}
+    xr = x.double().requires_grad_(True)
+    yr = O.coord_attn(xr, P, "ca", train)
+    (yr * probe.double()).sum().backward()
+    ref = {"y": yr.detach(), "dx": xr.grad, "y_nograd": yr.detach()}
+    ref.update({"d." + k[3:]: v.grad.reshape(-1) for k, v in P.items() if v.is_floating_point() and v.requires_grad})
+    if train:
+        ref.update({"buf." + k[3:]: v for k, v in P.items() if "running" in k})
+    worst = {}
+    for k, r_ in ref.items():
+        scale = float(r_.abs().max()) + 1e-12
+        ef = float((fu[k].double() - r_).abs().max()) / scale
+        worst[k] = ef
+        bar = 2e-4 if not train else 2e-3          # fp32 kernels vs float64; train-mode BatchNorm over few rows amplifies rounding
+        if un is not None:
+            eu = float((un[k].double() - r_).abs().max()) / scale
+            assert ef <= max(bar, 3 * eu), (k, ef, eu)
+        else:
+            assert ef <= bar, (k, ef)
+    print(f"CoordAttn B{B} C{C} {H}x{W} train={train}: worst rel err vs float64 oracle {max(worst.values()):.2e} ({max(worst, key=worst.get)})")
