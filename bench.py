@@ -216,6 +216,26 @@ def cpu_baseline(args):
                                      f"{t_ms * 1e3:.0f} ms; {n_it} timed iters each, full size (no scaling)"}}
 
 
+FAMILIES = (   # (family, substrings of kernel names) — first match wins
+    ("conv", ("conv3x3_halo_kernel", "conv_tap4_halo_kernel", "conv_pw_kernel", "conv_igemm", "splitk_epilogue")),
+    ("wgrad", ("wgrad3x3_halo_kernel", "wgrad_reduce", "wgrad_pw_kernel", "conv_wgrad")),
+    ("batchnorm", ("bn_act_fwd", "bn_bwd_reduce", "bn_bwd_apply", "bn_finalize", "col_reduce", "col_stats")),
+    ("optimiser", ("adamw", "sumsq", "pack_multi", "scatter_copy", "scaler_update", "pack_w")),
+    ("attention", ("se_fwd", "se_bwd", "ca_z_", "ca_mix", "ca_bwd", "ca_gate", "ca_pix", "strip_reduce", "strip_fold", "scale_res", "dense_", "sgemm",
+                   "act_fwd", "act_bwd", "sigmix", "colsum_small")),
+    ("glue", ("upcat", "film", "gn_", "avgpool", "nchw", "nhwc", "qsample", "loss_", "randn", "draw_ts", "onehot", "cast_kernel", "add_kernel", "unpad",
+              "maxpool", "cat_", "mask_axpy", "fill_t", "cfg_update")),
+    ("torch", ("at::native", "_ZN2at", "rocclr")),
+)
+
+
+def family_of(name):
+    for fam, keys in FAMILIES:
+        if any(k in name for k in keys):
+            return fam
+    return "other"
+
+
 def self_launch(argv, n):
     """`python bench.py --gpus N` outside torchrun: this parent makes NO GPU call (torch.cuda.device_count() does not initialise
     HIP on this image); it starts N fresh child processes — one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set —
@@ -267,11 +287,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--size", type=int, default=64)
-    ap.add_argument("--n-feat", dest="n_feat", type=int, default=128)
-    ap.add_argument("--bottleneck-k", dest="bottleneck_k", type=int, default=4)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg5"],
+                    help="cfg2 (default): BASELINE configs[1] — 64x64, n_feat 128, k 4, bf16, B 64 per GPU.  cfg5: BASELINE configs[4] — 128x128, "
+                         "n_feat 256, k 8, fp16 (loss-scaled), B 8 per GPU.  The flags below override single values")
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--n-feat", dest="n_feat", type=int, default=None)
+    ap.add_argument("--bottleneck-k", dest="bottleneck_k", type=int, default=None)
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32", "fp16"])
     ap.add_argument("--sample-steps", dest="sample_steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
     ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=0, help="batch of the CPU-baseline legs (default: --batch, i.e. the stated B=64)")
@@ -291,6 +314,13 @@ def main():
     ap.add_argument("--force-dp", dest="force_dp", action="store_true",
                     help="run the RCCL gradient all-reduce path even with one rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
+    preset = {"cfg2": dict(batch=64, size=64, n_feat=128, bottleneck_k=4, dtype="bf16"),
+              "cfg5": dict(batch=8, size=128, n_feat=256, bottleneck_k=8, dtype="fp16")}[args.config]
+    for k_, v_ in preset.items():
+        if getattr(args, k_) is None:
+            setattr(args, k_, v_)
+    if args.config == "cfg5" and args.cpu and not args.cpu_batch:
+        args.cpu_batch = 1                     # a B=8 cfg-5 train step is ~13 TFLOP on the CPU: one sample, scaled (stated in the line)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not under torchrun: be the launcher (no GPU call has been made in this process)
@@ -431,6 +461,31 @@ def main():
         torch.distributed.all_gather_object(devices, f"cuda:{local} ({torch.cuda.get_device_properties(local).name})")
     ranks_seen = torch.distributed.get_world_size() if use_dp else 1
 
+    # ---- one MORE step, outside the timed region, with an event pair around EVERY kernel of the plan: per-family times, the
+    # whole-step roofline and the HBM-bound table (the ~1100 event records of such a step cost milliseconds of wall time, so it
+    # must not sit inside the timed region; the dominant kernel's events above do)
+    fam_ms, fam_n, kern_ms, step_kernel_ms = {}, {}, {}, None
+    if planned and not no_events:
+        if reducer is not None:
+            graphed._runner = lambda pl: reducer.replay(pl, run=lambda a, b: pl.run_timed("", a, b))
+        else:
+            graphed._runner = lambda pl: pl.run_timed("")
+        train_step()
+        graphed._runner = reducer.replay if reducer is not None else None
+        allres = graphed.plan.timed_results(cap=16384)
+        step_kernel_ms = 0.0
+        for (_, nm, ms) in allres:
+            fam = family_of(nm)
+            fam_ms[fam] = fam_ms.get(fam, 0.0) + ms
+            fam_n[fam] = fam_n.get(fam, 0) + 1
+            short = nm.split("(")[0]
+            for key in ("bn_bwd_apply", "bn_bwd_reduce", "bn_act_fwd", "adamw_kernel", "sumsq_kernel", "pack_multi", "wgrad_reduce"):
+                if key in nm:
+                    short = key
+            k_ = kern_ms.setdefault(short, [0.0, 0])
+            k_[0] += ms; k_[1] += 1
+            step_kernel_ms += ms
+
     # ---- roofline of the dominant kernel family (implicit-GEMM conv fwd/dgrad + wgrad) from the events
     fl = {"conv_igemm": [0.0, 0.0, 0], "conv_wgrad": [0.0, 0.0, 0]}
     shapes = {}
@@ -450,37 +505,82 @@ def main():
     # dominant kernel: conv3x3_halo_kernel (forward + input gradient of the 3x3 layers) when the run used it, else the gather kernel
     fl.setdefault("conv_halo", [0.0, 0.0, 0])
     dom = "conv_halo" if fl["conv_halo"][2] else "conv_igemm"
-    allconv = [fl["conv_igemm"][k] + fl["conv_halo"][k] for k in range(3)]
     peak = PEAK_BF16_TFLOPS if dtype != torch.float32 else PEAK_F32_TFLOPS     # fp16 and bf16 MFMA run at the same dense rate
     ach = fl[dom][0] / max(fl[dom][1], 1e-12) / 1e12
+    # algorithmic FLOPs / bytes of the captured step (ops.PROFILE_META: one record per MFMA launch and per BatchNorm pass)
+    meta = graphed.conv_meta if graphed is not None else []
+    flops_conv = sum(m[1] for m in meta if m[0] in ("conv_halo", "conv_igemm", "igemm_f32"))
+    flops_wgrad = sum(m[1] for m in meta if m[0] in ("wgrad_halo", "conv_wgrad", "wgrad_f32"))
+    flops_step = flops_conv + flops_wgrad
+    ms_step = elapsed / args.steps * 1e3
+    # algorithmic bytes of the dominant kernel's launches: input read once + weights + output written once
+    esz = 4 if dtype == torch.float32 else 2
+    alg_bytes = None
+    if dom == "conv_halo" and meta:
+        tot = 0.0
+        for m in meta:
+            if m[0] != "conv_halo":
+                continue
+            # shape string "B{B} {Hi}x{Wi} C{C1}+{C2} N{N} T{T} s{sy} t{ty}"
+            tk = m[2].split()
+            B_ = int(tk[0][1:]); Hi_, Wi_ = [int(v) for v in tk[1].split("x")]; C1_, C2_ = [int(v) for v in tk[2][1:].split("+")]
+            N_ = int(tk[3][1:]); T_ = int(tk[4][1:])
+            tot += esz * (B_ * Hi_ * Wi_ * (C1_ + C2_) + N_ * T_ * (C1_ + C2_) + B_ * Hi_ * Wi_ * N_)
+        alg_bytes = tot / max(1, sum(1 for m in meta if m[0] == "conv_halo"))
     # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes over this same
     # command (they cannot be collected from inside the process); the committed summary is quoted when present
     traffic, traffic_src = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")) as f:
-            pmc = json.load(f)["kernels"].get("conv3x3_halo<bf16>" if dtype == torch.bfloat16 else "", None)
-        if pmc and args.n_feat == 128 and args.size == 64 and args.batch == 64:
-            traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r02_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this command, scripts/pmc_collect.sh)"
-    except (OSError, KeyError, ValueError):
-        pass
+    for cand in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", cand)) as f:
+                pmc = json.load(f)["kernels"].get("conv3x3_halo<bf16>" if dtype == torch.bfloat16 else "", None)
+            if pmc and args.n_feat == 128 and args.size == 64 and args.batch == 64:
+                traffic = pmc["hbm_bytes_per_launch"]
+                traffic_src = f"profiles/{cand}: a QUOTE of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command (scripts/pmc_collect.sh), not measured by this run"
+                break
+        except (OSError, KeyError, ValueError):
+            continue
+
+    def fam_rate(fam, flops):
+        t = fam_ms.get(fam)
+        return None if not t else round(flops / (t * 1e-3) / 1e12, 2)
+    hbm_rows = []
+    if fam_ms:
+        n_par = opt.total
+        alg = {"bn_bwd_apply": sum(m[1] for m in meta if m[0] == "bn_bwd_apply"), "bn_bwd_reduce": sum(m[1] for m in meta if m[0] == "bn_bwd_reduce"),
+               "bn_act_fwd": sum(m[1] for m in meta if m[0] == "bn_fwd"), "adamw_kernel": 30.0 * n_par, "sumsq_kernel": 4.0 * n_par}
+        cand = sorted(((k_, v_) for k_, v_ in kern_ms.items() if k_ in alg and alg[k_] > 0), key=lambda kv: -kv[1][0])[:4]
+        for k_, (ms_, n_) in cand:
+            hbm_rows.append({"kernel": k_, "launches": n_, "ms_per_step": round(ms_, 4), "algorithmic_bytes_per_step": int(alg[k_]),
+                             "achieved_GBps": round(alg[k_] / (ms_ * 1e-3) / 1e9, 1), "frac_of_8TBps": round(alg[k_] / (ms_ * 1e-3) / 8e12, 4)})
     roofline = {"bound": "mfma", "kernel": ("conv3x3_halo_kernel<%s> (dm_conv forward + input-gradient launches of the 3x3 layers)" if dom == "conv_halo"
                                             else "conv_igemm2_kernel<%s> (dm_conv forward + input-gradient launches)") % args.dtype,
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (avg)", "traffic_source": traffic_src,
                 "traffic_kernel": "conv3x3_halo_kernel",
-                "algorithmic_bytes_per_launch": "input read once + weights + output written once = 67-201 MB on the 64^2 layers, 34-50 MB on 32^2..8^2",
+                "algorithmic_bytes_per_launch": None if alg_bytes is None else int(alg_bytes),
+                "algorithmic_bytes_note": "average over this kernel's launches of: input read once + weights + output written once",
                 "launches": fl[dom][2], "avg_launch_us": round(fl[dom][1] / max(fl[dom][2], 1) * 1e6, 2),
                 "algorithmic_tflop_per_step": round(fl[dom][0] / prof_steps / 1e12, 4),
-                "all_dm_conv": {"achieved": round(allconv[0] / max(allconv[1], 1e-12) / 1e12, 2), "launches": allconv[2],
-                                "algorithmic_tflop_per_step": round(allconv[0] / prof_steps / 1e12, 4),
-                                "note": "every bf16 dm_conv launch of the step incl. 4x4/s2, 1x1 and ConvTranspose on the gather kernel"},
-                "wgrad": {"achieved": round(fl["conv_wgrad"][0] / max(fl["conv_wgrad"][1], 1e-12) / 1e12, 2),
-                          "launches": fl["conv_wgrad"][2],
-                          "algorithmic_tflop_per_step": round(fl["conv_wgrad"][0] / prof_steps / 1e12, 4)},
-                "mfma_time_share_of_step": round((allconv[1] + fl["conv_wgrad"][1]) / prof_steps / (elapsed / args.steps), 4),
-                "events": ("HIP event pairs on the launch stream around every halo-kernel launch of the last timed step (dm_plan_run_timed; the gather-"
-                           "kernel launches are not timed in this mode, so all_dm_conv / wgrad cover the halo kernels only)") if planned else
-                          "HIP events on the launch stream around every MFMA launch of the last timed step"}
+                "events": ("HIP event pairs on the launch stream around every halo-kernel launch of the LAST TIMED step (dm_plan_run_timed)") if planned else
+                          "HIP events on the launch stream around every MFMA launch of the last timed step",
+                "wgrad_halo": {"achieved": round(fl["conv_wgrad"][0] / max(fl["conv_wgrad"][1], 1e-12) / 1e12, 2), "launches": fl["conv_wgrad"][2],
+                               "algorithmic_tflop_per_step": round(fl["conv_wgrad"][0] / prof_steps / 1e12, 4),
+                               "note": "wgrad3x3_halo_kernel launches only (its reduce kernel is in families.wgrad)"},
+                # the whole step against the same peak: every algorithmic FLOP of the step / the step time `value` is computed from
+                "step": {"tflop": round(flops_step / 1e12, 4), "ms": round(ms_step, 3), "achieved": round(flops_step / (ms_step * 1e-3) / 1e12, 2),
+                         "frac": round(flops_step / (ms_step * 1e-3) / 1e12 / peak, 4)},
+                # one extra step AFTER the timed region with an event pair around every kernel of the plan
+                "families": None if not fam_ms else {
+                    "source": "one extra replay of the step outside the timed region, HIP event pair around every kernel (dm_plan_run_timed(\"\"))",
+                    "kernel_ms_per_step": round(step_kernel_ms, 3), "launches": sum(fam_n.values()),
+                    "ms": {k_: round(v_, 4) for k_, v_ in sorted(fam_ms.items(), key=lambda kv: -kv[1])}, "n": fam_n,
+                    "all_dm_conv": {"achieved": fam_rate("conv", flops_conv), "algorithmic_tflop_per_step": round(flops_conv / 1e12, 4),
+                                    "note": "every dm_conv kernel of the step: halo, four-tap, pointwise, gather, split-K epilogues"},
+                    "all_wgrad": {"achieved": fam_rate("wgrad", flops_wgrad), "algorithmic_tflop_per_step": round(flops_wgrad / 1e12, 4),
+                                  "note": "every weight-gradient kernel incl. the reduce launches"},
+                    "non_mfma_ms": round(sum(v_ for k_, v_ in fam_ms.items() if k_ not in ("conv", "wgrad")), 4)},
+                "hbm_bound": hbm_rows}
 
     # ---- CFG sampling rate (not part of `value`): every rank samples its shard of n = batch x world images (no exchange inside the
     # trajectory); steady-state step rate = difference of two runs, so the one-off graph capture of sample() cancels out
@@ -507,6 +607,14 @@ def main():
             rate = args.sample_steps / max(t_long - t_short, 1e-9)
             sample = {"steps_per_s": round(rate, 3), "n": n * world, "denoiser_batch_per_gpu": 2 * n, "guide_w": 2.0, "hipgraph": True,
                       "encoder_dedup": True, "steps_timed": args.sample_steps, "images_x_steps_per_s": round(rate * n * world, 1)}
+            if flops_step:
+                # forward FLOPs per sample = a third of the train step's; with the encoder + up0 (51.6 % of the MACs) computed
+                # once for the two CFG halves a step is n * (0.516 + 2 * 0.484) forwards
+                fwd = flops_step / 3.0 / args.batch
+                tfl = fwd * n * (0.516 + 2 * 0.484) / 1e12
+                sample["algorithmic_tflop_per_step_per_gpu"] = round(tfl, 4)
+                sample["achieved_tflops_per_gpu"] = round(tfl * rate, 2)
+                sample["frac_of_mfma_peak"] = round(tfl * rate / peak, 4)
         except Exception as exc:              # noqa: BLE001 — reported in the JSON
             sample = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         ddpm.train()
@@ -522,7 +630,8 @@ def main():
                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "new_scripy.py ContextUnet %dx%d n_feat=%d T=1000 %s, train step batch=%d per GPU (BASELINE configs[%d])"
-                                      % (args.size, args.size, args.n_feat, args.dtype, args.batch, 1 if world == 1 else 2),
+                                      % (args.size, args.size, args.n_feat, args.dtype, args.batch, 4 if args.config == "cfg5" else (1 if world == 1 else 2)),
+                          "preset": args.config,
                           "global_batch": args.batch * world, "bottleneck_k": args.bottleneck_k, "n_classes": 4,
                           "parallelism": "dp%d" % world, "backend": args.backend if use_dp else None, "exec": mode, "host_ms_one_step_idle_queue": round(t_host_one * 1e3, 3), "samples_per_s": round(value * args.batch, 2)},
                "loss": final_loss, "roofline": roofline, "cpu_baseline": cpu, "sample": sample}

@@ -422,6 +422,7 @@ bool halo_eligible(const ConvP& p) {
 
 // 0: not eligible; 1: the 4x4 / stride-2 / pad-1 forward form (S2); 2: a 2x2-tap stride-1 gather with offsets in {-1, 0, 1}
 // (the input gradient of one output-parity class of that layer).  Output image rows of 8 (four images per tile), 16, 32 or 64 pixels.
+int g_conv_persist = 1;
 int g_tap4 = 1;
 int tap4_mode(const ConvP& p) {
     if (!g_tap4 || p.C2 != 0 || p.C1 % 64 != 0 || p.N < 64 || p.B2 != p.B) return 0;
@@ -524,6 +525,9 @@ int launch_splitk_epilogue128(const ConvP& q, bool is_f16, unsigned grid, hipStr
 
 }  // namespace dmk
 using namespace dmk;
+
+/* 1 (default): 3x3 launches with more tiles than CUs run as persistent workgroups with cross-tile prefetch (igemm_halo_p.hip) */
+extern "C" int dm_set_conv_persist(int on) { dmk::g_conv_persist = on ? 1 : 0; return DM_OK; }
 
 extern "C" int dm_set_conv_tap4(int on) { g_tap4 = (on & 1) != 0; g_pw = (on & 2) == 0; return DM_OK; }   // bit 1 set: pointwise kernel off too
 extern "C" int dm_set_splitk_inkernel(int on) { g_splitk_inkernel = on != 0; return DM_OK; }

@@ -214,6 +214,16 @@ int launch_halo(const ConvP& p, hipStream_t st) {
             q.counters = g_splitk_inkernel ? dm_g_counters : nullptr;   // the last split to arrive runs the epilogue in the same launch
         }
     }
+    if (q.splits == 1 && g_conv_persist) {          // persistent workgroups with cross-tile prefetch (igemm_halo_p.hip) where they apply
+        static int ncu = 0;
+        if (ncu == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+            if (ncu <= 0) ncu = 256;
+        }
+        if (halo_persist_ok(q, tiles, ncu)) return launch_halo_persist_any(q, std::is_same<T, f16>::value, tiles, ncu, st);
+    }
     hipLaunchKernelGGL((conv3x3_halo_kernel<T, TW, FLIP>), dim3((unsigned)(tiles * q.splits)), dim3(512), HALO_LDS, st, q);
     DM_LAUNCH_CHECK();
     g_last_path = 1;

@@ -125,9 +125,12 @@ extern "C" int dm_plan_from_graph(void* hip_graph, void** plan_out) {
         PlanOp op{};
         if (ty == hipGraphNodeTypeKernel) {
             e = hipGraphKernelNodeGetParams(nodes[u], &op.k);
-            if (e != hipSuccess || op.k.func == nullptr || (op.k.kernelParams == nullptr && op.k.extra == nullptr)) {
+            // the replay launches with hipLaunchKernel(func, ..., kernelParams, ...): a node whose arguments live in `extra`
+            // (hipModuleLaunchKernel-style) would be launched with a null argument block -> refused, loudly
+            if (e != hipSuccess || op.k.func == nullptr || op.k.kernelParams == nullptr) {
                 delete p;
-                dm_set_error("dm_plan_from_graph: kernel node %d has no replayable parameters (%s)", u, hipGetErrorString(e));
+                dm_set_error("dm_plan_from_graph: kernel node %d has no kernelParams array (%s%s): not replayable", u, hipGetErrorString(e),
+                             (e == hipSuccess && op.k.extra != nullptr) ? "; its arguments are in `extra`" : "");
                 return DM_EUNSUPPORTED;
             }
             if (op.k.func == (void*)plan_marker_kernel) {
@@ -194,7 +197,7 @@ extern "C" int dm_plan_op_name(void* plan, int idx, char* buf, int cap) {
     return op.kind;
 }
 
-static int plan_issue(const PlanOp& op, hipStream_t st) {
+static int plan_issue(const PlanOp& op, hipStream_t st, int idx = -1) {
     hipError_t e = hipSuccess;
     if (op.kind == 0) {
         e = hipLaunchKernel(op.k.func, op.k.gridDim, op.k.blockDim, op.k.kernelParams, op.k.sharedMemBytes, st);
@@ -203,8 +206,33 @@ static int plan_issue(const PlanOp& op, hipStream_t st) {
         else if (op.ms.elementSize == 2) e = hipMemsetD16Async((hipDeviceptr_t)op.ms.dst, (unsigned short)op.ms.value, op.ms.width, st);
         else e = hipMemsetAsync(op.ms.dst, (int)op.ms.value, op.ms.width, st);
     }
-    if (e != hipSuccess) { dm_set_error("dm_plan_run: op failed: %s", hipGetErrorString(e)); return (int)e; }
+    if (e != hipSuccess) {
+        // (the launches before op `idx` have been issued: the step is half-way — the caller must not keep training on this state)
+        dm_set_error("dm_plan_run: op %d (%s) failed: %s; ops before it were issued", idx,
+                     op.kind == 0 ? hipKernelNameRefByPtr(op.k.func, nullptr) : "memset", hipGetErrorString(e));
+        return (int)e;
+    }
     return DM_OK;
+}
+
+// does the kernel name contain one of the '|'-separated substrings of `list` ("" matches everything)
+static bool name_hit(const char* nm, const char* list) {
+    if (!nm) return false;
+    if (!*list) return true;
+    const char* a = list;
+    while (*a) {
+        const char* b = strchr(a, '|');
+        const size_t n = b ? (size_t)(b - a) : strlen(a);
+        if (n > 0 && n < 200) {
+            char buf[200];
+            memcpy(buf, a, n);
+            buf[n] = 0;
+            if (strstr(nm, buf)) return true;
+        }
+        if (!b) break;
+        a = b + 1;
+    }
+    return false;
 }
 
 /* issue segments [seg_first, seg_last] on `stream` (marker launches themselves are not replayed) */
@@ -218,7 +246,7 @@ extern "C" int dm_plan_run(void* plan, int seg_first, int seg_last, dm_stream_t 
     hipStream_t st = (hipStream_t)stream;
     for (int i = lo; i < hi; ++i) {
         if (p->ops[i].kind == 2) continue;
-        const int rc = plan_issue(p->ops[i], st);
+        const int rc = plan_issue(p->ops[i], st, i);
         if (rc != DM_OK) return rc;
     }
     return DM_OK;
@@ -241,11 +269,11 @@ extern "C" int dm_plan_run_timed(void* plan, int seg_first, int seg_last, const 
         bool hit = false;
         if (op.kind == 0) {
             const char* nm = hipKernelNameRefByPtr(op.k.func, nullptr);
-            hit = nm && strstr(nm, substr) != nullptr;
+            hit = name_hit(nm, substr);            // '|'-separated list of substrings; "" = every kernel
         }
         hipEvent_t a = nullptr, b = nullptr;
         if (hit) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
-        const int rc = plan_issue(op, st);
+        const int rc = plan_issue(op, st, i);
         if (hit) { (void)hipEventRecord(b, st); p->timed_events.push_back(a); p->timed_events.push_back(b); p->timed_ops.push_back(i); }
         if (rc != DM_OK) return rc;
     }

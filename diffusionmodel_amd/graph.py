@@ -45,7 +45,8 @@ class LaunchPlan:
         L.call("dm_plan_run", self._h, int(first), int(self.n_segments - 1 if last is None else last))
 
     def run_timed(self, substr, first=0, last=None):
-        """run() with a HIP event pair around every kernel whose name contains `substr` (read them with timed_results())."""
+        """run() with a HIP event pair around every kernel whose name contains one of the '|'-separated substrings of `substr`
+        ("" = every kernel); read them with timed_results()."""
         L.call("dm_plan_run_timed", self._h, int(first), int(self.n_segments - 1 if last is None else last), substr.encode())
 
     def timed_results(self, cap=8192):
@@ -187,6 +188,11 @@ class GraphedTrainStep:
         if attn_mask is not None:
             self.am.copy_(attn_mask, non_blocking=True)
         self.opt.sync_hyper()                              # picks up a changed lr / weight decay (outside the graph)
+        if ops.ZERO_ARENA.off:
+            # an eager train-mode forward / backward that was not followed by opt.step() (a logging pass, a partial accumulation
+            # group) left non-zero sums in arena slices the captured step will use as zeroed accumulators: the replay zeroes
+            # the arena only at its END, so put it back in the state the capture assumed
+            ops.ZERO_ARENA.recycle()
         self._replay()
         for sp, d in zip(self._specs, self._nbt):          # host-side bookkeeping one replay stands for
             sp.nbt_pending += d

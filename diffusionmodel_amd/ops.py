@@ -123,6 +123,11 @@ class _StashGrad(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.fork.stash is not None:
+            # the earlier consumer's backward never took the previous stash: a second backward over the same graph
+            # (retain_graph=True), or autograd.grad on a sub-graph that excludes the earlier consumer — the gradient would be lost
+            raise L.DmError("GradFork: the stashed gradient of a forked tensor was never consumed (a second backward pass over the "
+                            "same graph, or a sub-graph without the tensor's first consumer, is not supported on the HIP path)")
         ctx.fork.stash = g.contiguous()
         return None, None
 
@@ -503,6 +508,8 @@ class ConvBnAct(torch.autograd.Function):
             _conv_call(x, x2, ptr(wp), T * Cp, z, shift=b, psum=st[0], psq=st[1], stat_slots=slots, **geom)
             call("dm_bn_act_fwd_slots", ptr(z), ptr(out), dt(dtype), M, N, ptr(st[0]), ptr(st[1]), slots, BN_EPS, bn.momentum, ptr(gamma), ptr(beta),
                  spec.act, ptr(mean), ptr(rstd), ptr(bn.running_mean), ptr(bn.running_var))
+            if PROFILE_META is not None:           # algorithmic bytes of the streaming pass: read z, write a
+                PROFILE_META.append(("bn_fwd", 2.0 * M * N * z.element_size(), f"M{M} N{N}"))
             spec.nbt_pending += 1
             bn._stat_epoch = getattr(bn, "_stat_epoch", 0) + 1
         else:
@@ -518,6 +525,8 @@ class ConvBnAct(torch.autograd.Function):
                 _conv_call(x, x2, ptr(wp), T * Cp, z, shift=b, **geom)
                 mean, rstd = _running_stats(bn, N)
             call("dm_bn_act_fwd", ptr(z), ptr(out), dt(dtype), M, N, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), spec.act)
+            if PROFILE_META is not None:
+                PROFILE_META.append(("bn_fwd", 2.0 * M * N * z.element_size(), f"M{M} N{N}"))
         ctx.train = train
         ctx.save_for_backward(x, x2, w, z, mean, rstd, gamma, beta)
         return out
@@ -535,6 +544,9 @@ class ConvBnAct(torch.autograd.Function):
             g = g.contiguous()
             dbeta, dgamma = _empty((N,), torch.float32, g), _empty((N,), torch.float32, g)
             dz = _empty(z.shape, dtype, g)
+            if PROFILE_META is not None:           # reduce: read z, dy; apply: read z, dy, write dz
+                PROFILE_META.append(("bn_bwd_reduce", 2.0 * M * N * z.element_size(), f"M{M} N{N}"))
+                PROFILE_META.append(("bn_bwd_apply", 3.0 * M * N * z.element_size(), f"M{M} N{N}"))
             slots = BN_SLOTS if (ctx.train and N % (4 if dtype == torch.float32 else 8) == 0 and N <= BN_SLOTS_MAX_C) else 0
             if slots:      # sums of g and g*xhat as [slots][N] accumulators folded by the apply kernel (which also emits dbeta / dgamma)
                 pp = _gzeros((2, slots, 2 * N), g)           # [2][slots][N] doubles
@@ -793,7 +805,9 @@ class Linear(torch.autograd.Function):
         db = _gzeros((N,), x) if (ctx.has_b and ctx.needs_input_grad[2]) else None
         _lin_bwd(x, w, g, dx, dw, db)
         stash = ctx.fork.take() if ctx.fork is not None else None
-        if stash is not None and dx is not None:
+        if stash is not None and dx is None:
+            raise L.DmError("Linear backward: a gradient was stashed for the forked input, but the input needs no gradient here")
+        if stash is not None:
             call("dm_add", ptr(dx), ptr(stash.reshape(dx.shape).contiguous()), ptr(dx), L.DM_F32, dx.numel())
         return dx, dw, db, None
 
@@ -1076,7 +1090,7 @@ class CaChain(torch.autograd.Function):
                 sp.nbt_pending += 1
                 bn._stat_epoch = getattr(bn, "_stat_epoch", 0) + 1
         if need_grad:
-            ctx.save_for_backward(xh, xw, zh, zw, *saved, *mats, gh_, bh_, gw_, bw_, gam_h, gam_w)
+            ctx.save_for_backward(xh, xw, zh, zw, *saved, *mats, gh_, bh_, gw_, bw_, gam_h, gam_w, bhw, bwh)
             ctx.meta = (B, H, W, Cc, R, train, float(mod.bn1_h.momentum), [t is not None for t in (b1h, b1w, bhw, bwh, bch, bcw)],
                         [tuple(t.shape) for t in (w1h, w1w, whw, wwh, wch, wcw)])
         return lh, lw
@@ -1084,7 +1098,7 @@ class CaChain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlh, dlw):
         (xh, xw, zh, zw, mean_h, rstd_h, mean_w, rstd_w, ah, aw, xhp, xwp, w1h, w1w, whw, wwh, wch, wcw, gh_, bh_, gw_, bw_, gam_h,
-         gam_w) = ctx.saved_tensors
+         gam_w, bhw, bwh) = ctx.saved_tensors
         B, H, W, Cc, R, train, mom, has_b, wshapes = ctx.meta
         dlh, dlw = dlh.contiguous(), dlw.contiguous()
         d = L.DmCaChain()
@@ -1100,6 +1114,7 @@ class CaChain(torch.autograd.Function):
         d_gam = gz(2)
         d.xh, d.xw, d.zh, d.zw = ptr(xh), ptr(xw), ptr(zh), ptr(zw)
         d.w1h, d.w1w, d.whw, d.wwh, d.wch, d.wcw = ptr(w1h), ptr(w1w), ptr(whw), ptr(wwh), ptr(wch), ptr(wcw)
+        d.bhw, d.bwh = ptr(bhw), ptr(bwh)          # the projections are recomputed in the backward pass (d gamma needs them)
         d.bn_h_g, d.bn_h_b, d.bn_w_g, d.bn_w_b, d.gam_h, d.gam_w = ptr(gh_), ptr(bh_), ptr(gw_), ptr(bw_), ptr(gam_h), ptr(gam_w)
         d.mean_h, d.rstd_h, d.mean_w, d.rstd_w, d.ah, d.aw, d.xhp, d.xwp = [ptr(t) for t in (mean_h, rstd_h, mean_w, rstd_w, ah, aw, xhp, xwp)]
         d.dlh, d.dlw, d.gh, d.gw, d.bnpart, d.dh2w, d.dw2h, d.dxh, d.dxw = [ptr(t) for t in (dlh, dlw, g_h, g_w, bnpart, dh2w, dw2h, dxh, dxw)]

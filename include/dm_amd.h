@@ -73,6 +73,9 @@ int dm_conv(const DmConv* d, dm_stream_t stream);
 int dm_conv_parity4(const DmConv* d4, dm_stream_t stream);
 /* tuning knob: staging pipeline of dm_conv — 1 = register staging, 2..4 = LDS-DMA gather ring with that many stages,
    5 (default) = halo-resident kernel for 3x3 stride-1 layers on 16/32/64-pixel rows with 64-channel multiples, gather ring otherwise */
+/* 1 (default): 3x3 stride-1 launches with more output tiles than CUs run as PERSISTENT workgroups that fetch the next tile's first
+ * halo chunk and weight stages behind the last chunk of the current tile (igemm_halo_p.hip); 0: one workgroup per tile. */
+int dm_set_conv_persist(int on);
 int dm_set_conv_variant(int variant);
 /* which kernel family the last dm_conv call launched: 0 = gather kernel (conv_igemm*), 1 = conv3x3_halo_kernel (profiling aid) */
 int dm_last_conv_path(void);
@@ -384,14 +387,17 @@ int dm_scatter_copy(const int64_t* table_dev, int n_entries, int add, dm_stream_
  * CUDAGraph with keep_graph=True) — the captured hipGraph is never instantiated — and hands the hipGraph_t over:
  * dm_plan_from_graph reads every kernel / memset node back (function, grid, block, argument block) in dependency order.
  * Nodes stay owned by the graph: keep it (and the memory pool of the capture) alive as long as the plan.
- * memcpy / host / child-graph nodes are refused (DM_EUNSUPPORTED): copies inside a planned step go through library kernels.
+ * memcpy / host / child-graph nodes are refused (DM_EUNSUPPORTED): copies inside a planned step go through library kernels;
+ * so are kernel nodes without a kernelParams array (arguments in `extra`).  A failing launch makes dm_plan_run return with the
+ * failing op's index and name in dm_last_error(); the ops before it HAVE been issued.
  *   dm_plan_marker          launched INSIDE the capture: ends a segment; the host may act between segments on replay
  *                           (the data-parallel all-reduce of a finished gradient bucket); not replayed itself
  *   dm_plan_info            info[6] = {ops, kernel launches, memsets, markers, skipped ordering-only nodes, segments}
  *   dm_plan_segment_marker  id of the marker that ends segment `seg` (-1 for the last segment)
  *   dm_plan_op_name         kernel name of op `idx` into buf (diagnostics); returns 0 kernel / 1 memset / 2 marker / -1
  *   dm_plan_run             issue segments [seg_first, seg_last] on `stream`
- *   dm_plan_run_timed       dm_plan_run with a HIP event pair on `stream` around every kernel whose name contains `substr`
+ *   dm_plan_run_timed       dm_plan_run with a HIP event pair on `stream` around every kernel whose name contains one of the
+ *                           '|'-separated substrings of `substr` ("" = every kernel)
  *   dm_plan_timed_results   synchronises `stream`; ms_out[i] / op_out[i] = duration and op index of the i-th timed launch since
  *                           the last call                                                                                    */
 int dm_plan_marker(int id, dm_stream_t stream);

@@ -1,7 +1,7 @@
 #!/bin/bash
 set -o pipefail
 O=gpurun_out
-python -m pytest tests/test_gpu_kernels.py -x -q -s -k "fused_coordattn or fused_se" > $O/t3.log 2>&1; echo "pytest rc $?" | tee -a $O/t3.log
+python -m pytest tests/test_gpu_kernels.py -q -s -k "fused_coordattn or fused_se" > $O/t3.log 2>&1; echo "pytest rc $?" | tee -a $O/t3.log
 tail -25 $O/t3.log
 {
 echo "== conv probe, one process"; DM_DEVICE_GUARD=0 timeout -k 5 120 python scripts/share_conv_probe.py solo 1500
