@@ -217,7 +217,7 @@ def cpu_baseline(args):
 
 
 FAMILIES = (   # (family, substrings of kernel names) — first match wins
-    ("conv", ("conv3x3_halo_kernel", "conv_tap4_halo_kernel", "conv_pw_kernel", "conv_igemm", "splitk_epilogue")),
+    ("conv", ("conv3x3_halo_kernel", "conv3x3_halo_pkernel", "conv_tap4_halo_kernel", "conv_pw_kernel", "conv_igemm", "splitk_epilogue")),
     ("wgrad", ("wgrad3x3_halo_kernel", "wgrad_reduce", "wgrad_pw_kernel", "conv_wgrad")),
     ("batchnorm", ("bn_act_fwd", "bn_bwd_reduce", "bn_bwd_apply", "bn_finalize", "col_reduce", "col_stats")),
     ("optimiser", ("adamw", "sumsq", "pack_multi", "scatter_copy", "scaler_update", "pack_w")),
@@ -414,9 +414,9 @@ def main():
         if last and planned:
             plan = graphed.plan
             if reducer is not None:
-                graphed._runner = lambda pl: reducer.replay(pl, run=lambda a, b: pl.run_timed("halo_kernel", a, b))
+                graphed._runner = lambda pl: reducer.replay(pl, run=lambda a, b: pl.run_timed("halo_kernel|halo_pkernel", a, b))
             else:
-                graphed._runner = lambda pl: pl.run_timed("halo_kernel")
+                graphed._runner = lambda pl: pl.run_timed("halo_kernel|halo_pkernel")
             loss = train_step()
             graphed._runner = reducer.replay if reducer is not None else None
             continue
@@ -434,7 +434,7 @@ def main():
         res = graphed.plan.timed_results()
         meta_conv = [m for m in graphed.conv_meta if m[0] == "conv_halo"]
         meta_wg = [m for m in graphed.conv_meta if m[0] == "wgrad_halo"]
-        got_conv = [r for r in res if "conv3x3_halo_kernel" in r[1]]
+        got_conv = [r for r in res if "conv3x3_halo_kernel" in r[1] or "conv3x3_halo_pkernel" in r[1]]
         got_wg = [r for r in res if "wgrad3x3_halo_kernel" in r[1]]
         if len(got_conv) != len(meta_conv) or len(got_wg) != len(meta_wg):
             raise SystemExit(f"bench: the plan holds {len(got_conv)}/{len(got_wg)} halo conv/wgrad launches, the capture recorded {len(meta_conv)}/{len(meta_wg)}")

@@ -423,6 +423,7 @@ bool halo_eligible(const ConvP& p) {
 // 0: not eligible; 1: the 4x4 / stride-2 / pad-1 forward form (S2); 2: a 2x2-tap stride-1 gather with offsets in {-1, 0, 1}
 // (the input gradient of one output-parity class of that layer).  Output image rows of 8 (four images per tile), 16, 32 or 64 pixels.
 int g_conv_persist = 1;
+int g_last_persist = 0;          // 1: the last dm_conv launch was the persistent form of the halo kernel
 int g_tap4 = 1;
 int tap4_mode(const ConvP& p) {
     if (!g_tap4 || p.C2 != 0 || p.C1 % 64 != 0 || p.N < 64 || p.B2 != p.B) return 0;
@@ -539,6 +540,7 @@ extern "C" int dm_set_conv_variant(int variant) {
 }
 
 extern "C" int dm_last_conv_path(void) { return g_last_path; }
+extern "C" int dm_last_conv_persistent(void) { return dmk::g_last_persist; }
 extern "C" int dm_get_conv_variant(void) { return g_variant; }
 
 static int conv_fill(const DmConv* d, ConvP& p, bool& small);
@@ -626,6 +628,7 @@ static int conv_fill(const DmConv* d, ConvP& p_out, bool& small_out) {
 
 extern "C" int dm_conv(const DmConv* d, dm_stream_t stream) {
     g_last_path = 0;
+    g_last_persist = 0;
     ConvP p;
     bool small;
     const int rc = conv_fill(d, p, small);

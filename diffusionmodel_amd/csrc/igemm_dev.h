@@ -369,6 +369,7 @@ constexpr int SRD_FLAGS = 0x00020000;
 extern int g_splitk_inkernel;        // igemm.hip
 extern int g_last_path;              // igemm.hip: kernel family of the last dm_conv launch
 int launch_halo_any(const ConvP& p, bool is_f16, hipStream_t st);                          // igemm_halo.hip
+extern int g_last_persist;
 extern int g_conv_persist;           // igemm.hip: 1 = persistent halo kernel where halo_persist_ok()
 bool halo_persist_ok(const ConvP& p, int tiles, int ncu);                                  // igemm_halo_p.hip
 int launch_halo_persist_any(const ConvP& p, bool is_f16, int tiles, int ncu, hipStream_t st);

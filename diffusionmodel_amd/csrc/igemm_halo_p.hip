@@ -169,11 +169,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pkernel(const ConvP p, const
     issue_w(wc, 0, 0);
     issue_w(wc, C2, 1);
     // byte offset of the NEXT weight stage to fetch, (tap * C + 64 chunk) * 2, advanced by scalar adds the optimiser cannot
-    // re-derive into nine hoisted multiples of C (asm volatile)
+    // re-derive into nine hoisted multiples of C (asm volatile).  The adds write SCC: declared, or the compiler keeps the chunk
+    // loop's exit compare live across them (first build: an endless chunk loop whenever a tile had >= 3 chunks)
     int wso = 2 * C2;
     auto wso_step = [&](int tap) {                         // after the issue of tap + 2: on to tap + 3 (or tap 0 of the next chunk)
-        if ((tap + 3) % 9 == 0) asm volatile("s_sub_u32 %0, %0, %1\n\ts_add_u32 %0, %0, 0x80" : "+s"(wso) : "s"(8 * C2));
-        else asm volatile("s_add_u32 %0, %0, %1" : "+s"(wso) : "s"(C2));
+        if ((tap + 3) % 9 == 0) asm volatile("s_sub_u32 %0, %0, %1\n\ts_add_u32 %0, %0, 0x80" : "+s"(wso) : "s"(8 * C2) : "scc");
+        else asm volatile("s_add_u32 %0, %0, %1" : "+s"(wso) : "s"(C2) : "scc");
     };
     int cbuf = 0;
     bool first_tile = true;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pkernel(const ConvP p, const
                 if (tap == 7) wso = 0;                               // the next tile starts at chunk 0, tap 0
                 if (tap + 2 >= 9) issue_w(wn_, wso, t2 % 3);
                 else issue_w(wc, wso, t2 % 3);
-                if (tap + 2 >= 9) asm volatile("s_add_u32 %0, %0, %1" : "+s"(wso) : "s"(C2));
+                if (tap + 2 >= 9) asm volatile("s_add_u32 %0, %0, %1" : "+s"(wso) : "s"(C2) : "scc");
                 else wso_step(tap);
                 if (tap < 7) issue_h(hn1, tap, 0, cbuf ^ 1);
                 mma_tap(tap);
@@ -261,7 +262,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pkernel(const ConvP p, const
 
 // the 8-stores-per-wave epilogue (igemm_dev.h conv_store, `wide`) and a reason to be persistent at all
 bool halo_persist_ok(const ConvP& p, int tiles, int ncu) {
-    if (tiles <= ncu || p.N % 128 != 0 || p.out_nchw) return false;
+    // at least three tiles per workgroup: with two (the 32x32 layers at B = 64: 36 k-steps per tile) the cross-tile prefetch gains
+    // less than the longer code path costs (same-box A/B: 64x64 128->128 -4 .. -6 %, 64x64 128->256 -6.6 %, 32x32 256->256 +1.5 .. +2.7 %)
+    if (tiles < 3 * ncu || p.N % 128 != 0 || p.out_nchw) return false;
     if (((p.ldc | p.coff) & 7) != 0 || ((uintptr_t)p.out & 15) != 0 || ((uintptr_t)p.addend & 15) != 0) return false;
     if (p.C2 != 0 || p.C1 % 64 != 0 || p.B2 != p.B) return false;     // single source, whole chunks
     return true;
@@ -280,6 +283,7 @@ static int launch_halo_p(const ConvP& p, int tiles, int ncu, hipStream_t st) {
     hipLaunchKernelGGL((conv3x3_halo_pkernel<T, TW, FLIP>), dim3((unsigned)ncu), dim3(512), HALO_LDS, st, q, tiles);
     DM_LAUNCH_CHECK();
     g_last_path = 1;
+    g_last_persist = 1;
     return DM_OK;
 }
 

@@ -76,6 +76,7 @@ int dm_conv_parity4(const DmConv* d4, dm_stream_t stream);
 /* 1 (default): 3x3 stride-1 launches with more output tiles than CUs run as PERSISTENT workgroups that fetch the next tile's first
  * halo chunk and weight stages behind the last chunk of the current tile (igemm_halo_p.hip); 0: one workgroup per tile. */
 int dm_set_conv_persist(int on);
+int dm_last_conv_persistent(void);   /* 1: the last dm_conv launch ran the persistent form */
 int dm_set_conv_variant(int variant);
 /* which kernel family the last dm_conv call launched: 0 = gather kernel (conv_igemm*), 1 = conv3x3_halo_kernel (profiling aid) */
 int dm_last_conv_path(void);

@@ -11,7 +11,7 @@ import csv
 import json
 import sys
 
-FAMILIES = [("conv_tap4_halo<bf16>", "conv_tap4_halo_kernel"), ("conv_pw<bf16>", "conv_pw_kernel"), ("conv3x3_halo<bf16>", "conv3x3_halo_kernel"), ("conv_igemm2<bf16>", "conv_igemm2_kernelIDF16b"), ("wgrad3x3_halo<bf16>", "wgrad3x3_halo_kernel"),
+FAMILIES = [("conv_tap4_halo<bf16>", "conv_tap4_halo_kernel"), ("conv_pw<bf16>", "conv_pw_kernel"), ("conv3x3_halo<bf16>", "conv3x3_halo_"), ("conv_igemm2<bf16>", "conv_igemm2_kernelIDF16b"), ("wgrad3x3_halo<bf16>", "wgrad3x3_halo_kernel"),
             ("wgrad_reduce", "wgrad_reduce_kernel"), ("splitk_epilogue<bf16>", "splitk_epilogue_kernelIDF16b"), ("conv_wgrad2<bf16>", "conv_wgrad2_kernelIDF16b"),
             ("bn_act_fwd<bf16>", "bn_act_fwd_slots_kernelIDF16b"), ("bn_bwd_reduce<bf16>", "bn_bwd_reduce_kernelIDF16b"),
             ("bn_bwd_apply<bf16>", "bn_bwd_apply_slots_kernelIDF16b"), ("adamw", "adamw_kernel")]

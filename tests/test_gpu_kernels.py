@@ -957,8 +957,8 @@ def test_fused_coordattn_chain_matches_the_oracle_and_the_unfused_path(B, C, H, 
 
 
 # ---- persistent halo kernel (igemm_halo_p.hip): cross-tile prefetch, counted waits over the epilogue's stores ----------------------
-@pytest.mark.parametrize("B,H,C,N,dtype", [(32, 64, 64, 128, torch.bfloat16), (20, 64, 128, 128, torch.float16), (64, 32, 128, 256, torch.bfloat16),
-                                           (136, 16, 192, 384, torch.bfloat16), (264, 8, 64, 640, torch.bfloat16), (6, 128, 64, 128, torch.bfloat16)])
+@pytest.mark.parametrize("B,H,C,N,dtype", [(52, 64, 64, 128, torch.bfloat16), (50, 64, 128, 128, torch.float16), (100, 32, 128, 256, torch.bfloat16),
+                                           (264, 16, 192, 384, torch.bfloat16), (620, 8, 64, 640, torch.bfloat16), (13, 128, 64, 128, torch.bfloat16)])
 def test_persistent_halo_kernel_is_bit_identical_to_one_workgroup_per_tile(B, H, C, N, dtype):
     """conv3x3_halo_pkernel walks over several tiles per workgroup and fetches the next tile's halo / weights behind the current
     tile's last chunk; the k order of a tile is the one-workgroup-per-tile kernel's, so forward, input gradient (with and without
@@ -986,7 +986,7 @@ def test_persistent_halo_kernel_is_bit_identical_to_one_workgroup_per_tile(B, H,
         conv.weight, conv.bias = w, bias
         spec = o.ConvSpec(3, 3, 1, 1, o.ACT_GELU if with_bn else o.ACT_NONE, bn if with_bn else None)
         y = o.conv_bn_act(xd, None, conv, bn if with_bn else None, spec, fork if C == N else None)
-        paths = [lib.dm_last_conv_path()]
+        paths = [lib.dm_last_conv_path(), lib.dm_last_conv_persistent()]
         loss = (y.float() * probe.float()).sum()
         if C == N:                                             # x feeds a second consumer: its gradient joins in the dgrad epilogue (addend)
             loss = loss + ((fork.second(xd).float() + 0.0 * y.float()) * 0.5).sum()   # (consumes y too: its backward runs before the conv's)
@@ -994,8 +994,9 @@ def test_persistent_halo_kernel_is_bit_identical_to_one_workgroup_per_tile(B, H,
         return [y.detach().clone(), xd.grad.clone(), w.grad.clone(), bias.grad.clone(), bn.running_var.clone()], paths
     try:
         for with_bn in (False, True):
-            a, _ = run(1, with_bn)
-            b_, _ = run(0, with_bn)
+            a, pa = run(1, with_bn)
+            b_, pb = run(0, with_bn)
+            assert pa == [1, 1] and pb == [1, 0], (pa, pb)             # the forward launch took the persistent / the per-tile halo kernel
             for name, u, v in zip(("y", "dx", "dw", "db", "running_var"), a, b_):
                 if name in ("y", "dx") and not with_bn:
                     assert torch.equal(u, v), (with_bn, name, float((u.float() - v.float()).abs().max()))
@@ -1007,7 +1008,7 @@ def test_persistent_halo_kernel_is_bit_identical_to_one_workgroup_per_tile(B, H,
 
 def test_persistent_halo_kernel_exact_integers():
     o = ops()
-    B, C, N, H = 24, 128, 128, 64                               # 384 tiles on 256 CUs: workgroups with one and with two tiles
+    B, C, N, H = 52, 128, 128, 64                               # 832 tiles on 256 CUs: workgroups with three and with four tiles
     g = torch.Generator().manual_seed(77)
     ri = lambda *s: torch.randint(-1, 2, s, generator=g).float()
     x, w, b, probe = ri(B, C, H, H), ri(N, C, 3, 3), ri(N), ri(B, N, H, H)
