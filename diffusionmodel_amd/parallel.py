@@ -70,6 +70,7 @@ def guard_shared_device(local, group=None, identity=None):
 
 
 SHARED_DEVICE = [False]
+_NOCOMM = os.environ.get("DM_DP_NOCOMM") == "1"
 
 
 def bucket_bounds(total, n_buckets, align=1024):
@@ -225,6 +226,8 @@ class OverlappedGradReducer:
             torch.cuda.synchronize()
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())          # the weight gradients launched so far
+            if _NOCOMM:                                                    # (measurement aid: the choreography without the collectives)
+                return
             with torch.cuda.stream(self._stream):
                 self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
@@ -355,7 +358,8 @@ class OverlappedGradReducer:
             elif m == self.MARK_SMALL_PACKED:
                 if self._drain:
                     torch.cuda.synchronize()
-                dist.all_reduce(self._packed, op=dist.ReduceOp.SUM, group=self.group)
+                if not _NOCOMM:
+                    dist.all_reduce(self._packed, op=dist.ReduceOp.SUM, group=self.group)
             elif m != -1:
                 raise DmError(f"OverlappedGradReducer.replay: unknown plan marker {m}")
 

@@ -5,7 +5,7 @@ import csv
 import json
 import sys
 
-FAMILIES = [("conv3x3_halo", "conv3x3_halo_kernel"), ("conv_igemm2", "conv_igemm2_kernel"), ("conv_tap4_halo", "conv_tap4_halo_kernel"), ("conv_pw", "conv_pw_kernel"),
+FAMILIES = [("conv3x3_halo_persistent", "conv3x3_halo_pkernel"), ("conv3x3_halo", "conv3x3_halo_kernel"), ("conv_igemm2", "conv_igemm2_kernel"), ("conv_tap4_halo", "conv_tap4_halo_kernel"), ("conv_pw", "conv_pw_kernel"),
             ("wgrad3x3_halo", "wgrad3x3_halo_kernel"), ("conv_wgrad2", "conv_wgrad2_kernel"), ("wgrad_reduce", "wgrad_reduce_kernel"),
             ("bn_act_fwd", "bn_act_fwd"), ("bn_bwd_reduce", "bn_bwd_reduce"), ("bn_bwd_apply", "bn_bwd_apply")]
 
