@@ -46,7 +46,9 @@ __device__ __forceinline__ F4 mm_bigK(XF xf, const float* __restrict__ W, int ld
     const int r = lane & 15, g = lane >> 4;
     F4 acc[4] = {z4(), z4(), z4(), z4()};
     const int nck = (K + 15) >> 4;
-    for (int c0 = wave; c0 < nck; c0 += 8) {             // chunks c0, c0 + 4: 10 loads in flight
+    // chunks c0, c0 + 4 per pass: 10 loads in flight (four chunks per pass — 20 loads — measured SLOWER on every kernel that
+    // uses this: 47 vs 29 us on ca_bwd_mix, 17 vs 9 on ca_z; the W^T form holds 64 scalar loads and their addresses then)
+    for (int c0 = wave; c0 < nck; c0 += 8) {
         F4 fx[2], fw[2][4];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -68,25 +70,34 @@ __device__ __forceinline__ F4 mm_bigK(XF xf, const float* __restrict__ W, int ld
 // out[16][N] = X[16][K] W^T, short K (<= 128), X in LDS (row stride ldx floats): wave w takes the 16-column fragments
 // f = w, w + 4, ...; epi(n4, acc): acc[v] = out[r][n4 + v], n4 = 16 f + 4 g
 template <bool WT, typename EPI>
-__device__ __forceinline__ void mm_bigN(const float* xl, int ldx, const float* __restrict__ W, int ldw, int N, int K, int wave, int lane, EPI epi) {
+__device__ __forceinline__ void mm_bigN(const float* xl, int ldx, const float* __restrict__ W, int ldw, int N, int K, int wave, int lane, EPI epi,
+                                        int part = 0, int nparts = 1) {
+    // `part` of `nparts`: the fragments are dealt out over workgroups too (f = 4 part + wave, step 4 nparts)
     const int r = lane & 15, g = lane >> 4;
     const int nf = (N + 15) >> 4, nck = (K + 15) >> 4;
-    for (int f = wave; f < nf; f += 4) {
-        F4 acc = z4();
+    const int fstep = 4 * nparts;
+    for (int f0 = 4 * part + wave; f0 < nf; f0 += 2 * fstep) {     // two fragments per pass: their weight loads are in flight together
+        F4 acc[2] = {z4(), z4()};
+        const bool two = f0 + fstep < nf;
         for (int c0 = 0; c0 < nck; c0 += 4) {
-            F4 fw[4], fx[4];
+            F4 fw[2][4], fx[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int kb4 = (c0 + u) * 16 + 4 * g;
-                fw[u] = wfrag<WT>(W, ldw, 16 * f + r, kb4, N, K);
+                fw[0][u] = wfrag<WT>(W, ldw, 16 * f0 + r, kb4, N, K);
+                fw[1][u] = two ? wfrag<WT>(W, ldw, 16 * (f0 + fstep) + r, kb4, N, K) : z4();
                 fx[u] = kb4 < K ? *(const F4*)(xl + r * ldx + kb4) : z4();
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc = DM_MFMA4(fw[u][j], fx[u][j], acc);
+                for (int j = 0; j < 4; ++j) {
+                    acc[0] = DM_MFMA4(fw[0][u][j], fx[u][j], acc[0]);
+                    acc[1] = DM_MFMA4(fw[1][u][j], fx[u][j], acc[1]);
+                }
         }
-        epi(16 * f + 4 * g, acc);
+        epi(16 * f0 + 4 * g, acc[0]);
+        if (two) epi(16 * (f0 + fstep) + 4 * g, acc[1]);
     }
 }
 
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(256) void se_fwd_kernel(const SeP p) {
             F4 s = *(const F4*)(p.parts + (size_t)m * p.C + kb4);
             for (int q = 1; q < p.RS; ++q) s += *(const F4*)(p.parts + q * bc + (size_t)m * p.C + kb4);
             s *= p.scale;
-            if (p.save && n_lo == 0) *(F4*)(p.y + (size_t)m * p.C + kb4) = s;
+            if (p.save && n_lo == 0 && blockIdx.y == 0) *(F4*)(p.y + (size_t)m * p.C + kb4) = s;
             return s;
         };
         const F4 h = mm_bigK<false>(xf, p.w1, p.C, n_lo, p.R, p.C, red, wave, lane);
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(256) void se_fwd_kernel(const SeP p) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) gv[v] = gelu_f(h[v]);
             *(F4*)(ghl + r * SE_LD + n4) = gv;
-            if (p.save && mok) {
+            if (p.save && mok && blockIdx.y == 0) {
                 *(F4*)(p.hid + (size_t)m * p.R + n4) = h;
                 *(F4*)(p.gh + (size_t)m * p.R + n4) = gv;
             }
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(256) void se_fwd_kernel(const SeP p) {
             for (int v = 0; v < 4; ++v) s[v] = sigmoid_f(acc[v]);
             *(F4*)(p.sg + (size_t)m * p.C + n4) = s;
         }
-    });
+    }, blockIdx.y, gridDim.y);
 }
 
 struct SeBP {
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(256) void se_bwd_rows_kernel(const SeBP p) {
             F4 d;
 #pragma unroll
             for (int v = 0; v < 4; ++v) d[v] = s[v] * p.scale * sg[v] * (1.f - sg[v]);
-            if (n_lo == 0) *(F4*)(p.dlogit + (size_t)m * p.C + kb4) = d;
+            if (n_lo == 0 && blockIdx.y == 0) *(F4*)(p.dlogit + (size_t)m * p.C + kb4) = d;
             return d;
         };
         const F4 dg = mm_bigK<true>(xf, p.w2, p.R, n_lo, p.R, p.C, red, wave, lane);
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(256) void se_bwd_rows_kernel(const SeBP p) {
                 const F4 h = *(const F4*)(p.hid + (size_t)m * p.R + n4);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) dh[v] = dg[v] * gelu_grad_f(h[v]);
-                *(F4*)(p.dhid + (size_t)m * p.R + n4) = dh;
+                if (blockIdx.y == 0) *(F4*)(p.dhid + (size_t)m * p.R + n4) = dh;
             }
             *(F4*)(dhl + r * SE_LD + n4) = dh;
         }
@@ -229,7 +240,7 @@ __global__ __launch_bounds__(256) void se_bwd_rows_kernel(const SeBP p) {
     __syncthreads();
     mm_bigN<true>(dhl, SE_LD, p.w1, p.C, p.C, p.R, wave, lane, [&](int n4, F4 acc) {
         if (mok && n4 < p.C) *(F4*)(p.dy + (size_t)m * p.C + n4) = acc;
-    });
+    }, blockIdx.y, gridDim.y);
 }
 
 // weights: dw2[c][r] += sum_b dlogit[b][c] gh[b][r];  dw1[r][c] += sum_b dhid[b][r] y[b][c]   (blocks [0, nA): dw2 tiles, then dw1 tiles)
@@ -334,6 +345,7 @@ __global__ __launch_bounds__(256) void ca_mix_kernel(const CaP p, int nbh, int n
     __shared__ double dsum[512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15;
     const int b = blockIdx.x, R = p.R, H = p.H, W = p.W;
+    const bool lead = blockIdx.y == 0;                      // grid.y deals out the C logits; one workgroup per sample owns the side effects
     float* Ah = sm;
     float* Aw = Ah + Hp * LD;
     float* H2W = Aw + Wp * LD;
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(256) void ca_mix_kernel(const CaP p, int nbh, int n
                 if (var < 0.0) var = 0.0;
                 mean[n] = (float)mu;
                 rstd[n] = (float)(1.0 / sqrt(var + (double)p.eps));
-                if (b == 0) {                               // one workgroup owns the side effects
+                if (b == 0 && lead) {                       // one workgroup owns the side effects
                     const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
                     rm[n] = (float)((1.0 - p.momentum) * (double)rm[n] + p.momentum * mu);
                     rv[n] = (float)((1.0 - p.momentum) * (double)rv[n] + p.momentum * unb);
@@ -373,7 +385,7 @@ __global__ __launch_bounds__(256) void ca_mix_kernel(const CaP p, int nbh, int n
         for (int n = threadIdx.x; n < R; n += 256) {
             mean[2 * R + n] = gm[n];
             mean[3 * R + n] = bt[n];
-            if (b == 0 && p.save) {
+            if (b == 0 && lead && p.save) {
                 (sIdx ? p.mean_w : p.mean_h)[n] = mean[n];
                 (sIdx ? p.rstd_w : p.rstd_h)[n] = rstd[n];
             }
@@ -392,7 +404,7 @@ __global__ __launch_bounds__(256) void ca_mix_kernel(const CaP p, int nbh, int n
             float v = 0.f;
             if (l < L) {
                 v = gelu_f((z[i] - mean[n]) * mean[R + n] * mean[2 * R + n] + mean[3 * R + n]);
-                if (p.save) ag[(size_t)b * L * R + i] = v;
+                if (p.save && lead) ag[(size_t)b * L * R + i] = v;
             }
             A[l * LD + n] = v;
         }
@@ -433,7 +445,7 @@ __global__ __launch_bounds__(256) void ca_mix_kernel(const CaP p, int nbh, int n
                 float t = 0.f;
                 for (int j = s0; j < e0; ++j) t += Oth[j * LD + n];
                 v = A[l * LD + n] + sg * (t / (float)(e0 - s0));
-                if (p.save) xg[(size_t)b * L * R + i] = v;
+                if (p.save && lead) xg[(size_t)b * L * R + i] = v;
             }
             X[l * LD + n] = v;
         }
@@ -452,7 +464,7 @@ __global__ __launch_bounds__(256) void ca_mix_kernel(const CaP p, int nbh, int n
                     if (bc) acc += *(const F4*)(bc + n4);
                     *(F4*)(lo + (size_t)(rb + r) * p.C + n4) = acc;
                 }
-            });
+            }, blockIdx.y, gridDim.y);
     }
 }
 
@@ -756,7 +768,8 @@ extern "C" int dm_ca_chain_fwd(const DmCaChain* d, dm_stream_t s) {
         attr = true;
     }
     hipLaunchKernelGGL(ca_z_kernel, dim3(nbh + nbw), dim3(256), 0, ST, *d, nbh);
-    hipLaunchKernelGGL(ca_mix_kernel, dim3(d->B), dim3(256), lds, ST, *d, nbh, nbw, Hp, Wp, LD);
+    const int ny = d->C >= 1024 ? 4 : (d->C >= 512 ? 2 : 1);      // wide layers: the C logits of a sample over several workgroups
+    hipLaunchKernelGGL(ca_mix_kernel, dim3(d->B, ny), dim3(256), lds, ST, *d, nbh, nbw, Hp, Wp, LD);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
@@ -799,7 +812,9 @@ extern "C" int dm_se_fwd(const void* x2, int dtype, int B, int HW, int C, const 
     p.scale = 1.f / (float)HW;
     p.w1 = w1; p.w2 = w2; p.y = y; p.hid = hid; p.gh = gh; p.sg = sg;
     p.B = B; p.C = C; p.R = R;
-    hipLaunchKernelGGL(se_fwd_kernel, dim3(cdiv(B, 16)), dim3(256), 0, ST, p);
+    // the hidden vector (a reduction over C) is recomputed by every workgroup of a row block; the C logits are dealt out over grid.y
+    const int ny = C >= 1024 ? 4 : (C >= 512 ? 2 : 1);
+    hipLaunchKernelGGL(se_fwd_kernel, dim3(cdiv(B, 16), ny), dim3(256), 0, ST, p);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
@@ -817,7 +832,8 @@ extern "C" int dm_se_bwd(const void* dout, const void* x2, int dtype, int B, int
     p.sg = sg; p.hid = hid; p.gh = gh; p.y = y; p.w1 = w1; p.w2 = w2;
     p.dlogit = dlogit; p.dhid = dhid; p.dy = dy; p.dw1 = dw1; p.dw2 = dw2;
     p.B = B; p.C = C; p.R = R;
-    hipLaunchKernelGGL(se_bwd_rows_kernel, dim3(cdiv(B, 16)), dim3(256), 0, ST, p);
+    const int ny = C >= 1024 ? 4 : (C >= 512 ? 2 : 1);
+    hipLaunchKernelGGL(se_bwd_rows_kernel, dim3(cdiv(B, 16), ny), dim3(256), 0, ST, p);
     const int kA = cdiv(R, 64), nA = kA * cdiv(C, 16), kB = cdiv(C, 64), nB = kB * cdiv(R, 16);
     hipLaunchKernelGGL(se_bwd_w_kernel, dim3(nA + nB), dim3(256), 0, ST, p, nA, kA, kB);
     DM_LAUNCH_CHECK();
