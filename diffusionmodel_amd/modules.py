@@ -227,21 +227,54 @@ class ResConvBlock(_HipBlock):
 ResidualConvBlock = ResConvBlock   # MNIST_script.py / scripy_old.py spelling
 
 
+class _PaddedBn(nn.BatchNorm2d):
+    """BatchNorm2d over `width` channels of which only the first `real.num_features` exist (UnetDown's compress branch when
+    in_ch // 4 is not a multiple of 8): a scratch holder the kernels write, mirrored from / to the registered module `real` around
+    every use.  Never registered as a submodule: the state_dict schema stays the reference's."""
+
+    def __init__(self, real, width):
+        super().__init__(width, eps=real.eps, momentum=real.momentum)
+        object.__setattr__(self, "_real", real)
+
+    def pull(self):
+        r, c = self._real, self._real.num_features
+        if self.running_mean.device != r.running_mean.device:
+            self.to(r.running_mean.device)
+        with torch.no_grad():
+            self.running_mean.zero_(); self.running_var.fill_(1.0)
+            self.running_mean[:c].copy_(r.running_mean); self.running_var[:c].copy_(r.running_var)
+            self.weight.fill_(1.0); self.bias.zero_()          # (the no-grad eval path folds the holder's own affine pair)
+            self.weight[:c].copy_(r.weight); self.bias[:c].copy_(r.bias)
+        self.train(r.training)
+        self._stat_epoch = getattr(self, "_stat_epoch", 0) + 1
+
+    def push(self):
+        r, c = self._real, self._real.num_features
+        if r.training:
+            with torch.no_grad():
+                r.running_mean.copy_(self.running_mean[:c]); r.running_var.copy_(self.running_var[:c])
+
+
 class UnetDown(_HipBlock):
     """new_scripy.py:211-235."""
 
     def __init__(self, in_ch, out_ch, compress_ratio=4):
         super().__init__()
         cc = in_ch // compress_ratio
-        if cc % 8 or out_ch % 8:
-            raise DmError(f"UnetDown({in_ch},{out_ch}): compressed channels {cc} must be a multiple of 8 on the HIP path "
-                          "(choose n_feat % 32 == 0)")
+        if cc % 4 or out_ch % 8:
+            raise DmError(f"UnetDown({in_ch},{out_ch}): compressed channels {cc} must be a multiple of 4 on the HIP path "
+                          "(choose n_feat % 16 == 0)")
         self.out_ch = out_ch
         self.channel_compress = nn.Sequential(_conv(in_ch, cc, 1), nn.BatchNorm2d(cc), nn.GELU())
         self.ch_adjust = _conv(cc, out_ch, 1)
         self.down = nn.Sequential(_conv(out_ch, out_ch, 3, 1, 1), nn.BatchNorm2d(out_ch), nn.GELU(),
                                   ResConvBlock(out_ch, out_ch, is_res=True), _conv(out_ch, out_ch, 4, 2, 1))
-        self._sp_cc = ops.ConvSpec(1, 1, 1, 0, ACT_GELU, self.channel_compress[1])
+        # cc % 8 != 0 (n_feat % 32 == 16): the compressed tensor is carried with cc rounded up to 8 channels — a masked 8-vector:
+        # zero weight rows / columns, gamma 1 and beta 0 on the extra channels keep them exactly zero through BatchNorm + GELU
+        self._cc, self._ccp = cc, (cc + 7) // 8 * 8
+        pad_bn = _PaddedBn(self.channel_compress[1], self._ccp) if self._ccp != cc else None
+        object.__setattr__(self, "_pad_bn", pad_bn)
+        self._sp_cc = ops.ConvSpec(1, 1, 1, 0, ACT_GELU, pad_bn if pad_bn is not None else self.channel_compress[1])
         self._sp_adj = ops.ConvSpec(1, 1, 1, 0)
         self._sp_d0 = ops.ConvSpec(3, 3, 1, 1, ACT_GELU, self.down[1])
         self._sp_d4 = ops.ConvSpec(4, 4, 2, 1)
@@ -249,10 +282,40 @@ class UnetDown(_HipBlock):
     def _out_channels(self):
         return self.out_ch
 
+    def _fwd_padded(self, x, fork):
+        """The compress branch with cc padded to a multiple of 8 (see __init__): padded copies of the four small parameters are built
+        per call (autograd slices their gradients back), BatchNorm runs on the scratch holder."""
+        import torch.nn.functional as F
+        cc, ccp = self._cc, self._ccp
+        conv, bn, adj, pb = self.channel_compress[0], self.channel_compress[1], self.ch_adjust, self._pad_bn
+        pb.pull()
+
+        class H:
+            pass
+        hc, ha = H(), H()
+        hc.weight = F.pad(conv.weight, (0, 0, 0, 0, 0, 0, 0, ccp - cc)).contiguous(memory_format=torch.channels_last)   # [ccp][C][1][1]
+        hc.bias = F.pad(conv.bias, (0, ccp - cc))
+        hb = H()
+        hb.weight = torch.cat([bn.weight, torch.ones(ccp - cc, device=bn.weight.device)])
+        hb.bias = F.pad(bn.bias, (0, ccp - cc))
+        ha.weight = F.pad(adj.weight, (0, 0, 0, 0, 0, ccp - cc)).contiguous(memory_format=torch.channels_last)          # [out][ccp][1][1]
+        ha.bias = adj.bias
+        need = torch.is_grad_enabled() and any(t.requires_grad for t in (x, hc.weight, hc.bias, hb.weight, hb.bias))
+        y = ops.ConvBnAct.apply(x, None, hc.weight, hc.bias, hb.weight, hb.bias, self._sp_cc, need, fork)
+        if pb.training:
+            n = self._sp_cc.nbt_pending                 # the batch counter belongs to the registered module
+            self._sp_cc.nbt_pending = 0
+            bn.num_batches_tracked += n
+        pb.push()
+        return ops.conv_bn_act(y, None, ha, None, self._sp_adj)
+
     def _fwd(self, x, fork=None):
         """`fork`: x is also a skip tensor (consumed again by the decoder)."""
-        x = ops.conv_bn_act(x, None, self.channel_compress[0], self.channel_compress[1], self._sp_cc, fork)
-        x = ops.conv_bn_act(x, None, self.ch_adjust, None, self._sp_adj)
+        if self._pad_bn is not None:
+            x = self._fwd_padded(x, fork)
+        else:
+            x = ops.conv_bn_act(x, None, self.channel_compress[0], self.channel_compress[1], self._sp_cc, fork)
+            x = ops.conv_bn_act(x, None, self.ch_adjust, None, self._sp_adj)
         x = ops.conv_bn_act(x, None, self.down[0], self.down[1], self._sp_d0)
         x = self.down[3]._fwd(x)
         return ops.conv_bn_act(x, None, self.down[4], None, self._sp_d4)
@@ -310,8 +373,8 @@ class ContextUnet(_HipBlock):
 
     def __init__(self, in_ch=3, n_feat=192, n_classes=10, bottleneck_k=None, dtype=None):
         super().__init__()
-        if n_feat % 32:
-            raise DmError(f"n_feat={n_feat}: the HIP path needs n_feat % 32 == 0 (channel vectors of 8)")
+        if n_feat % 16:
+            raise DmError(f"n_feat={n_feat}: the HIP path needs n_feat % 16 == 0 (the reference's own CoordAttn / SEBlock need channel // 16 >= 1)")
         k = Cfg.BOTTLENECK_K if bottleneck_k is None else bottleneck_k
         self.in_ch, self.n_feat, self.n_classes, self.bottleneck_k = in_ch, n_feat, n_classes, k
         F = n_feat
