@@ -603,8 +603,12 @@ def main():
         try:                                  # the sampling rate is a side figure: a failure here must not lose the train metric
             run(2)                                                                               # warm-up / caches
             k0 = 4
-            t_short, t_long = run(k0), run(k0 + args.sample_steps)
-            rate = args.sample_steps / max(t_long - t_short, 1e-9)
+            t_short = min(run(k0), run(k0))                # (two of each, the faster one: the capture cost varies from call to call)
+            t_long = min(run(k0 + args.sample_steps), run(k0 + args.sample_steps))
+            if t_long - t_short < 1e-4 * args.sample_steps:
+                raise RuntimeError(f"sampling timer: {args.sample_steps} extra steps took {t_long - t_short:.4f} s more than {k0} steps "
+                                   f"({t_short:.3f} s vs {t_long:.3f} s): capture cost dominates, raise --sample-steps")
+            rate = args.sample_steps / (t_long - t_short)
             sample = {"steps_per_s": round(rate, 3), "n": n * world, "denoiser_batch_per_gpu": 2 * n, "guide_w": 2.0, "hipgraph": True,
                       "encoder_dedup": True, "steps_timed": args.sample_steps, "images_x_steps_per_s": round(rate * n * world, 1)}
             if flops_step:
