@@ -113,7 +113,7 @@ def test_benchmark_width_f128_against_the_reference_fixture_bf16_and_fp32():
         m = f[mode]
         print(f"F=128 B=2 fp32 {mode}: max|eps - ref64| {m['eps_maxabs_vs_ref64']:.2e} (the reference's own fp32 run: {m['ref_fp32_maxabs']:.2e}); "
               f"loss {m['loss']:.6e} vs {m['loss_ref64']:.6e}; worst child grad-norm err {max(abs(v) for v in m['grad_norm_rel_err'].values()):.1e}")
-        assert m["eps_maxabs_vs_ref64"] <= (1e-4 if mode == "eval" else 3e-4)
+        assert m["eps_maxabs_vs_ref64"] <= 1e-4                 # north star, eval and train (measured 2.7e-6 / 4.6e-5; the reference's own fp32 run: 1.4e-6 / 3.3e-5)
         assert abs(m["loss"] - m["loss_ref64"]) <= 2e-6 + 1e-4 * abs(m["loss_ref64"])
         assert max(abs(v) for v in m["grad_norm_rel_err"].values()) <= (1e-3 if mode == "eval" else 1e-2)
     r = PL.f128_b2_case(torch.bfloat16)
