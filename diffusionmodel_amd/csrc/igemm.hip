@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvP p) {
     conv_epilogue<T, BN>(p, acc, smem, tid, wm, wn, fr, fg, mb, m0, n0);
 }
 
-int g_splitk_inkernel = 0;
+int g_splitk_inkernel = 1;   // r03: on (the sc1 hand-off of igemm_dev.h costs no fence); 0: separate split-K epilogue launches
 int g_last_path = 0;  // kernel family the last dm_conv launch used: 0 = gather (conv_igemm*), 1 = conv3x3_halo_kernel
 
 int g_variant = 5;    // 1 = register staging, 2..4 = LDS-DMA with that many ring stages (2 workgroups/CU at 2),

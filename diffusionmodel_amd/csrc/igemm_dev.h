@@ -44,34 +44,60 @@ __device__ __forceinline__ void store_partial(const ConvP& p, const f32x4 (&acc)
         for (int mt = 0; mt < 4; ++mt) dst[(nt * 4 + mt) * 64] = acc[nt][mt];
 }
 
-// Split-K without a second launch (halo kernels): every split parks its raw accumulators in ws (store_partial), publishes them
-// (release fence) and counts itself in; the split that arrives LAST (no spinning: whoever it is) adds the others' partials to
-// the accumulators it still holds in registers and runs the ordinary epilogue.  Returns false for the splits that are done.
+// Split-K without a second launch (halo kernels): every split parks its raw accumulators in ws, publishes them and counts itself
+// in; the split that arrives LAST (no spinning: whoever it is) adds the others' partials to the accumulators it still holds in
+// registers and runs the ordinary epilogue.  Returns false for the splits that are done.
+// r02 published through `__threadfence()` on both sides (buffer_wbl2 + buffer_inv: the XCD's whole L2 written back and the L1
+// invalidated per workgroup): the train step got 2 ms SLOWER.  r03: the cross-XCD hand-off of MI355X_MICROARCH.md (hand-off table,
+// first row): the partials are stored `sc1` (write-through, the line is dropped from the storing XCD's L2), every storing wave waits
+// for its stores, ONE lane adds to the tile's counter behind a workgroup barrier (agent-scope atomic), the workgroup whose add
+// came last — told by the value the add returned — loads the partials with `sc1` loads behind a workgroup barrier that lane joins.
+// No fence, no L2 write-back.  (The workspace lines cannot sit stale in the reader's L2: nothing on that XCD reads them in this
+// launch before the hand-off, and a launch boundary invalidates what earlier launches left.)
+__device__ __forceinline__ void st_sc1(f32x4* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void ld_sc1(f32x4& v, const f32x4* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory"); }
+
 __device__ __forceinline__ bool splitk_last_arriver(const ConvP& p, f32x4 (&acc)[4][4], char* smem, int split, int ntiles2, int tile_id,
                                                     int half_tile, int wave4, int tid, int lane) {
-    store_partial<128>(p, acc, split, ntiles2, half_tile, wave4, lane);
-    __threadfence();                                   // the partials are visible device-wide before the count says so
-    __syncthreads();
+    {
+        f32x4* dst = (f32x4*)p.ws + ((((size_t)split * ntiles2 + half_tile) * 4 + wave4) * 16) * 64 + lane;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) st_sc1(dst + (nt * 4 + mt) * 64, acc[nt][mt]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partials have left for memory
+    __syncthreads();                                   // ... and every other wave's of this workgroup
     int* flag = (int*)(smem + 16384);
     if (tid == 0) {
-        const int old = atomicAdd(p.counters + tile_id, 1);
+        const int old = __hip_atomic_fetch_add(p.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = old == p.splits - 1;
         if (last) p.counters[tile_id] = 0;             // everyone has arrived: ready for the next launch on this stream
         *flag = last;
     }
     __syncthreads();
     if (!*flag) return false;
-    __threadfence();                                   // acquire: the other splits' partials (written on other XCDs) are read from memory
+    // fold in the FIXED order k = 0 .. splits - 1 (this workgroup's own partial is read back like the others): the result does not
+    // depend on which split arrived last, and equals the two-launch epilogue's bit for bit (run-to-run reproducibility of the step)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < p.splits; ++k) {
-        if (k == split) continue;
         const f32x4* src = (const f32x4*)p.ws + ((((size_t)k * ntiles2 + half_tile) * 4 + wave4) * 16) * 64 + lane;
+        f32x4 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ld_sc1(v[i], src + i * 64);
+        // the loads are invisible to the compiler's counters: wait here, with the values as operands so that no use moves above it
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
+                       "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                     :
+                     : "memory");
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const f32x4 v = __builtin_nontemporal_load(src + (nt * 4 + mt) * 64);
-                acc[nt][mt] += v;
-            }
+            for (int mt = 0; mt < 4; ++mt) acc[nt][mt] += v[nt * 4 + mt];
     }
     __syncthreads();                                   // the flag word is LDS the epilogue reuses
     return true;

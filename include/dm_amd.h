@@ -115,9 +115,10 @@ int dm_set_wgrad_pw(int enable, int target_blocks, int min_pixels);
 /* bit 0: the 4x4 / stride-2 convolution and its input gradient on conv_tap4_halo_kernel (default on; 0 = gather kernel);
    bit 1: set = the short-K 1x1 layers stay on the gather kernel too (default: conv_pw_kernel).  Measurement knob. */
 int dm_set_conv_tap4(int on);
-/* halo kernels with the channel chunks split over workgroups: 0 (default) a separate epilogue launch folds the partials; 1 the last
-   split to arrive folds them and runs the epilogue in the same launch (arrival counters at the tail of the workspace) — measured
-   2 ms per train step slower: its agent-scope fences flush the XCD's L2 once per workgroup */
+/* halo kernels with the channel chunks split over workgroups: 1 (default since r03) the last split to arrive folds the partials and
+   runs the epilogue in the same launch (arrival counters at the tail of the workspace; partials handed over by sc1 stores, an
+   agent-scope counter add and sc1 loads — no fence); 0 a separate epilogue launch folds them.  (r02's form of 1 published through
+   agent-scope fences and was 2 ms per train step slower.) */
 int dm_set_splitk_inkernel(int on);
 /* Caller-owned device scratch (16-byte aligned) the MFMA kernels may use for split partial sums; it must outlive every
    launch that follows.  One stream at a time: launches that use it are ordered by the stream they are issued on. */

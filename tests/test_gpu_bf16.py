@@ -126,7 +126,10 @@ def test_benchmark_width_f128_against_the_reference_fixture_bf16_and_fp32():
         assert m["eps_mse_vs_ref64"] <= MARGIN * m["ref_autocast_bf16_mse"]
         assert m["eps_maxabs_vs_ref64"] <= 1.5 * m["ref_autocast_bf16_maxabs"]
         assert abs(m["loss"] - m["loss_ref64"]) <= 3 * _projection_noise(m["ref_autocast_bf16_mse"], m["probe_power"], m["n_elements"])
-        assert worst <= max(MARGIN * worst_ref, 0.02), (mode, m["grad_norm_rel_err"])
+        # one rounding-noise realisation against another at B = 2: the same build measured 0.046 .. 0.099 on the worst child (ca3 / down3:
+        # cancellation-heavy gate gradients) when only the fp32 summation order of the split-K layers changed; the reference's own
+        # autocast run sits at 0.046 / 0.091 (eval / train)
+        assert worst <= max(2.0 * worst_ref, 0.05), (mode, m["grad_norm_rel_err"])
 
 
 def test_cfg2_full_size_b64_train_forward_against_the_oracle():

@@ -689,8 +689,8 @@ def test_conv4x4s2_four_tap_halo_kernel_exact_integers(case, dtype):
 
 
 def test_splitk_last_arriver_form_is_bit_exact_too():
-    """dm_set_splitk_inkernel(1): the split that arrives last folds the others' partials and runs the epilogue in the same launch
-    (kept as an option; measured slower than the two-launch default because its device-scope fences flush the L2)."""
+    """dm_set_splitk_inkernel(1) — the default since r03: the split that arrives last folds the others' partials and runs the epilogue in
+    the same launch (sc1 stores / agent-scope counter / sc1 loads, no fence: igemm_dev.h); 0 = the two-launch form, also exact."""
     from diffusionmodel_amd import _lib
     lib = _lib.load()
     o = ops()
@@ -706,8 +706,12 @@ def test_splitk_last_arriver_form_is_bit_exact_too():
             for rep in range(3):                                  # the arrival counters must be back at zero after every launch
                 y = o.conv_bn_act(nhwc(x, torch.bfloat16), None, conv, None, o.ConvSpec(3, 3, 1, 1))
                 assert torch.equal(nchw(y), yr)
+            assert lib.dm_set_splitk_inkernel(0) == 0             # the two-launch form on the same problem
+            y = o.conv_bn_act(nhwc(x, torch.bfloat16), None, conv, None, o.ConvSpec(3, 3, 1, 1))
+            assert torch.equal(nchw(y), yr)
+            assert lib.dm_set_splitk_inkernel(1) == 0
     finally:
-        assert lib.dm_set_splitk_inkernel(0) == 0
+        assert lib.dm_set_splitk_inkernel(1) == 0
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
