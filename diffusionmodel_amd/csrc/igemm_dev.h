@@ -2,6 +2,11 @@
 // translation units of the family (igemm.hip: gather / pointwise kernels + dispatch; igemm_halo.hip: conv3x3_halo_kernel;
 // igemm_tap4.hip: conv_tap4_halo_kernel) so that they compile in parallel.
 #pragma once
+// Where the halo kernels issue the three LDS-DMA pieces of a k-step (2 weight pieces, 1 halo piece): 0 = right after the barrier,
+// next to the fragment reads; abc = before MFMA groups a, b, c of the k-step's 8 (4 MFMAs each; a <= b <= c keeps the vmcnt order).
+#ifndef DM_HALO_DMA_POS
+#define DM_HALO_DMA_POS 567
+#endif
 #include <type_traits>
 #include "common.h"
 

@@ -119,6 +119,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pkernel(const ConvP p, const
         for (int j = 0; j < 2; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_dst)(sW + stage * WSTAGE + (wave * 2 + j) * 1024), 16, wv[j], soff, 0, 0);
     };
+    auto issue_w1 = [&](const unsigned (&wv)[2], int j, int soff, int stage) {   // one of issue_w's two pieces
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_dst)(sW + stage * WSTAGE + (wave * 2 + j) * 1024), 16, wv[j], soff, 0, 0);
+    };
     const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc((void*)p.in1, 0, pix_img * p.C1 * 2, SRD_FLAGS);
     auto issue_h = [&](const unsigned (&h1)[7], int i, int chunk, int buf) {
         const int q = min(wave + 8 * i, NP - 1);
@@ -126,7 +129,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pkernel(const ConvP p, const
     };
 
     f32x4 acc[4][4];
-    auto mma_tap = [&](int tap) {
+    // `dma(g)` runs before MFMA group g = 4 sub + nt (4 MFMAs each): the k-step's LDS-DMA pieces are issued there, among MFMAs and
+    // away from the fragment reads (DM_HALO_DMA_POS, igemm_dev.h)
+    auto mma_tap = [&](int tap, auto&& dma) {
         const int ky = FLIP ? 2 - tap / 3 : tap / 3, kx = FLIP ? 2 - tap % 3 : tap % 3;
         const char* sWs = sW + (tap % 3) * WSTAGE;
 #pragma unroll
@@ -137,11 +142,15 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pkernel(const ConvP p, const
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) fa[nt] = *(const u32x4*)(sWs + woff[sub][nt]);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < 4; ++nt) {
+                dma(sub * 4 + nt);
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) Mma<T>::run(fa[nt], fb[mt], acc[nt][mt]);
+            }
         }
     };
+    constexpr int G0 = DM_HALO_DMA_POS ? DM_HALO_DMA_POS / 100 : -1, G1 = DM_HALO_DMA_POS ? DM_HALO_DMA_POS / 10 % 10 : -1,
+                  G2 = DM_HALO_DMA_POS ? DM_HALO_DMA_POS % 10 : -1;
     // wait before tap `tap`: everything older than the previous step's group has landed.  `after_epilogue`: chunk 0 of a tile that
     // follows another one in this workgroup — the previous tile's epilogue stores sit between the prefetch and this tap
     auto wait_tap = [&](int tap, bool after_epilogue) {
@@ -200,10 +209,21 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pkernel(const ConvP p, const
                 wait_tap(tap, ae);
                 __builtin_amdgcn_s_barrier();
                 const int t2 = (tap + 2) % 9;
+#if DM_HALO_DMA_POS == 0
                 issue_w(wc, wso, t2 % 3);
                 wso_step(tap);
                 if (tap < 7) issue_h(hc1, tap, chunk + 1, cbuf ^ 1);
-                mma_tap(tap);
+                mma_tap(tap, [](int) {});
+#else
+                mma_tap(tap, [&](int g) {
+                    if (g != G0 && g != G1 && g != G2) return;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g == G0) issue_w1(wc, 0, wso, t2 % 3);
+                    if (g == G1) { issue_w1(wc, 1, wso, t2 % 3); wso_step(tap); }
+                    if (g == G2 && tap < 7) issue_h(hc1, tap, chunk + 1, cbuf ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+#endif
             }
             swap_halo(hdelta);
             cbuf ^= 1;
@@ -218,12 +238,27 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pkernel(const ConvP p, const
                 __builtin_amdgcn_s_barrier();
                 const int t2 = (tap + 2) % 9;
                 if (tap == 7) wso = 0;                               // the next tile starts at chunk 0, tap 0
+#if DM_HALO_DMA_POS == 0
                 if (tap + 2 >= 9) issue_w(wn_, wso, t2 % 3);
                 else issue_w(wc, wso, t2 % 3);
                 if (tap + 2 >= 9) asm volatile("s_add_u32 %0, %0, %1" : "+s"(wso) : "s"(C2) : "scc");
                 else wso_step(tap);
                 if (tap < 7) issue_h(hn1, tap, 0, cbuf ^ 1);
-                mma_tap(tap);
+                mma_tap(tap, [](int) {});
+#else
+                mma_tap(tap, [&](int g) {
+                    if (g != G0 && g != G1 && g != G2) return;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g == G0) { if (tap + 2 >= 9) issue_w1(wn_, 0, wso, t2 % 3); else issue_w1(wc, 0, wso, t2 % 3); }
+                    if (g == G1) {
+                        if (tap + 2 >= 9) issue_w1(wn_, 1, wso, t2 % 3); else issue_w1(wc, 1, wso, t2 % 3);
+                        if (tap + 2 >= 9) asm volatile("s_add_u32 %0, %0, %1" : "+s"(wso) : "s"(C2) : "scc");
+                        else wso_step(tap);
+                    }
+                    if (g == G2 && tap < 7) issue_h(hn1, tap, 0, cbuf ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+#endif
             }
             swap_halo(hdelta);
             cbuf ^= 1;
