@@ -19,6 +19,11 @@
 // combine the splits — and accumulate into whatever dw already holds, which is how gradient
 // accumulation over micro-batches comes for free).  Blocks with y == 0 also produce dbias.
 #include "common.h"
+// Where the halo weight-gradient kernel issues the next tile's LDS-DMA pieces: 0 = all right after the tile's barrier; 0xAABB = the dy
+// pieces at slot AA, the halo pieces at slot BB, slot = 16 k-step + tap (issued before that tap's MFMAs).
+#ifndef DM_WGRAD_DMA_POS
+#define DM_WGRAD_DMA_POS 0x1111
+#endif
 
 namespace {
 
@@ -627,7 +632,8 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
             xright8 = hx8 - 1 == TW && lslot * 8 < Cs;
         }
     }
-    auto issue = [&](int stage, int tile) {
+    // `parts`: bit 0 = dy pieces 0, 1; bit 1 = dy pieces 2, 3; bit 2 = the first half of the wave's halo rows; bit 3 = the rest
+    auto issue = [&](int stage, int tile, int parts = 15) {
         char* sA = smem + stage * WGH_STAGE;
         char* sX = sA + WGH_DY;
         const int bimg = tile / tiles_img, trem = tile - bimg * tiles_img;
@@ -635,6 +641,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
         const int pix0 = TW == 8 ? tile * 128 : (bimg * p.Hi + y0) * RW + x0;       // first pixel of the tile
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                  // tile pixels 32 j .. 32 j + 31: (part of) one image row, or whole rows
+            if (!(parts & (j < 2 ? 1 : 2))) continue;
             const int prow = (TW == 64 && tcols > 1) ? pix0 + (j >> 1) * RW + (j & 1) * 32 : pix0 + j * 32;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rDY, (lds_dst3)(sA + (j * 8 + wave) * 1024), 16, dyv, prow * p.ldy * 2, 0, 0);
         }
@@ -646,6 +653,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
         if (halo_wave) {
 #pragma unroll
             for (int i = 0; i < RPG; ++i) {
+                if (!(parts & (i < RPG / 2 ? 4 : 8))) continue;
                 const int hy = hy0 + i;
                 // S2: halo row hy is sub-image row y0 + hy - py; rows 0 .. R are used
                 const bool row_ok = S2 ? !((py == 1 && hy == 0 && top) || (py == 0 && hy == R && bottom) || hy > R)
@@ -656,7 +664,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
             }
         }
         if constexpr (TW == 64) {
-            if (wave < 4) {
+            if (wave < 4 && (parts & 8)) {
                 const bool row_ok = !((wave == 0 && top) || (wave == HR - 1 && bottom));
                 const unsigned v = ((xok8 || (xright8 && has_right)) && row_ok) ? (unsigned)(tbase + xv8) : WG_OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_dst3)(sX + (wave * NC + 8) * 1024), 16, v, 0, 0, 0);
@@ -706,7 +714,9 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
         const int cur = (tile - t_lo) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();            // this tile has landed for every wave; the other stage is free again
+#if DM_WGRAD_DMA_POS == 0
         if (tile + 1 < t_hi) issue(cur ^ 1, tile + 1);
+#endif
         const char* sS = smem + cur * WGH_STAGE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -722,9 +732,25 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
                 fb[t] = tr_pair(sS + addrB[t % TPR][im] + koffB + ((t / TPR) * HS) * 128, HI);
             }
 #pragma unroll
-            for (int t = 0; t < NTAP; ++t)
+            for (int t = 0; t < NTAP; ++t) {
+#if DM_WGRAD_DMA_POS != 0
+                // the next tile's LDS-DMA pieces go between the MFMAs, after the k-step's fragment reads (an LDS-DMA piece costs 100-185
+                // issue cycles next to ds_reads, 25-60 among MFMAs: MI355X_MICROARCH.md): the dy pieces before tap (DY_SLOT & 15) of
+                // k-step (DY_SLOT >> 4), the halo pieces at X_SLOT
+                {
+                    constexpr int SD = DM_WGRAD_DMA_POS >> 8, SX = DM_WGRAD_DMA_POS & 255;
+                    constexpr int TD = (SD & 15) < NTAP ? (SD & 15) : NTAP - 1, TX = (SX & 15) < NTAP ? (SX & 15) : NTAP - 1;   // (stride-2 classes: 4 taps)
+                    const int pm = (ks == (SD >> 4) && t == TD ? 3 : 0) | (ks == (SX >> 4) && t == TX ? 12 : 0);
+                    if (pm != 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (tile + 1 < t_hi) issue(cur ^ 1, tile + 1, pm);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#endif
 #pragma unroll
                 for (int it = 0; it < 4; ++it) acc[it][t] = WMma<T>::run(fa[it], fb[t], acc[it][t]);
+            }
             // keep the k-steps apart: merged / hoisted halo reads push the kernel past 256 VGPRs, and a scratch reload in the
             // loop waits on vmcnt — i.e. on the next tile's DMA — which serialises staging and compute
             __builtin_amdgcn_sched_barrier(0);

@@ -952,6 +952,10 @@ def test_fused_coordattn_chain_matches_the_oracle_and_the_unfused_path(B, C, H, 
         ef = float((fu[k].double() - r_).abs().max()) / scale
         worst[k] = ef
         bar = 2e-4 if not train else 2e-3          # fp32 kernels vs float64; train-mode BatchNorm over few rows amplifies rounding
+        if k in ("d.alpha", "d.beta", "d.gamma_h", "d.gamma_w"):
+            # scalar gradients: ONE sum over B*C*H*W products of mixed sign, measured against the (cancelled) total — the fused
+            # chain folds it through fp32 atomics whose order changes from run to run (seen: 1.2e-4 and 2.1e-4 on the same case)
+            bar = max(bar, 1e-3)
         if un is not None:
             eu = float((un[k].double() - r_).abs().max()) / scale
             assert ef <= max(bar, 3 * eu), (k, ef, eu)
