@@ -216,7 +216,7 @@ def test_fp16_ddpm_forward_and_three_optimiser_steps_through_the_loss_scaler():
     print("fp16 train3 losses", t["losses"], "ref fp32", t["losses_ref"], "grad norms", t["grad_norms"], t["grad_norms_ref"])
     # Step 1 is tight and repeatable (5.8e-3 on the pre-clip gradient norm in every run).  Steps 2 and 3 are evaluated after AdamW
     # updates of +-lr per element (g / (|g| + eps) at t = 1, 2: a sign for every element), so fp16 rounding and the order of the fp32
-    # atomics flip the direction of near-zero elements: over seven runs of two builds (gpurun_out/fp16_spread.log) the second norm
+    # atomics flip the direction of near-zero elements: over seven runs of two builds (profiles/r03_fp16_three_step_spread.txt) the second norm
     # moved between 1.7e-4 and 1.1e-2, the third between 4.1e-2 and 6.2e-2.
     assert max(t["loss_rel_err"]) <= 6e-3 and t["grad_norm_rel_err"][0] <= 1e-2 and t["grad_norm_rel_err"][1] <= 3e-2 and t["grad_norm_rel_err"][2] <= 1e-1
     assert all(v["step"] == 3.0 for v in t["tensors"].values())                          # no step was skipped
