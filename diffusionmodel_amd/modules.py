@@ -441,3 +441,6 @@ class ContextUnet(_HipBlock):
 
     def forward(self, x, c, t, ctx_mask):
         return self.decode(self.encode(x), self.embed(c, t, ctx_mask))
+
+
+ops.refuse_second_backward(globals())

@@ -721,3 +721,95 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     assert out["config"]["global_batch"] == 32 and out["config"]["exec"] == "plan" and out["config"]["backend"] == "gloo"
     assert out["value"] > 0 and out["loss"] == out["loss"] and out["sample"]["n"] == 32 and "error" not in out["sample"]
     assert "ranks share 1 device" in r.stderr
+
+
+def test_replay_after_an_eager_backward_without_a_step_starts_from_clean_accumulators():
+    """the captured step uses slices of the process-wide zero arena as zeroed accumulators (BatchNorm slot sums, small
+    gradients) and re-zeroes the arena only at its END.  An eager train-mode forward + backward that is NOT followed by opt.step()
+    (a logging pass, a partial accumulation group) leaves sums in those slices; GraphedTrainStep.__call__ puts the arena back first.
+    The same replay — same weights, moments, BatchNorm buffers and noise counter — must give the same loss and gradient with and
+    without such a pass in front of it."""
+    import diffusionmodel_amd as D
+    from diffusionmodel_amd import ops
+
+    torch.manual_seed(11)
+    net = D.ContextUnet(3, 32, 4, bottleneck_k=4, dtype=torch.float32)
+    ddpm = D.DDPM(net, (1e-4, 0.02), 1, DEV, drop_prob=0.0).train()
+    ddpm.rng_seed = 5
+    opt = D.FusedAdamW(ddpm.parameters(), lr=1e-3, weight_decay=1e-5, max_grad_norm=1.0)
+    if not ops.ARENA_ENABLED[0]:
+        pytest.skip("another optimiser of this process is still alive: the gradient arena is off")
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(2, 3, 64, 64, generator=g).to(DEV)
+    c = torch.randint(0, 4, (2,), generator=g).to(DEV)
+    am = torch.ones(2, 64, 64).to(DEV)
+    step = D.GraphedTrainStep(ddpm, opt, x, c, am, mode="plan")
+
+    def snapshot():
+        return dict(p=opt.flat_p.clone(), m=opt.exp_avg.clone(), v=opt.exp_avg_sq.clone(), t=opt._step_dev.clone(), rng=ddpm._rng_dev.clone(),
+                    bufs=[b.clone() for b in ddpm.buffers()], step=opt._step, calls=ddpm._rng_calls, nbt=[sp.nbt_pending for sp in step._specs])
+
+    def restore(s):
+        with torch.no_grad():
+            opt.flat_p.copy_(s["p"]); opt.exp_avg.copy_(s["m"]); opt.exp_avg_sq.copy_(s["v"]); opt._step_dev.copy_(s["t"])
+            ddpm._rng_dev.copy_(s["rng"])
+            for b, b0 in zip(ddpm.buffers(), s["bufs"]):
+                b.copy_(b0)
+        opt._step, ddpm._rng_calls = s["step"], s["calls"]
+        for sp, n in zip(step._specs, s["nbt"]):
+            sp.nbt_pending = n
+        opt.refresh_shadow(); ops.bump_weight_epoch(); ops.refresh_packs()
+
+    s0 = snapshot()
+    loss1 = step().clone()
+    g1 = opt.flat_g.clone()
+    restore(s0)
+    ddpm(x, c, am).backward()                       # eager, train mode, no optimiser step
+    assert ops.ZERO_ARENA.off != 0                  # (what the test is about: the arena is in use)
+    restore(s0)                                     # (the eager pass advanced the noise counter and the BatchNorm buffers)
+    loss2 = step().clone()
+    g2 = opt.flat_g.clone()
+    rel = ((g1 - g2).norm() / g1.norm()).item()
+    print(f"replay after a dangling eager backward: loss {loss1.item():.6f} / {loss2.item():.6f}, gradient rel diff {rel:.2e}")
+    assert abs(loss1.item() - loss2.item()) <= 1e-5 * abs(loss1.item())
+    assert rel <= 1e-4, rel                         # fp32 atomics order only (dirty accumulators: O(1))
+
+
+def test_two_backward_passes_over_one_graph_match_or_fail_loudly():
+    """forked tensors (skip / residual / attention forks) hand the later consumer's gradient to the earlier consumer's
+    input-gradient kernel through a stash (ops.GradFork).  A second backward over the same graph (retain_graph=True) must either
+    produce the accumulated gradient (2 x) or raise — never drop the stashed half silently."""
+    import diffusionmodel_amd as D
+    from diffusionmodel_amd._lib import DmError
+
+    torch.manual_seed(3)
+    net = D.ContextUnet(3, 32, 4, bottleneck_k=4, dtype=torch.float32).to(DEV).train()
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(2, 3, 64, 64, generator=g).to(DEV)
+    c = torch.randint(0, 4, (2,), generator=g).to(DEV)
+    t = torch.rand(2, generator=g).to(DEV)
+    m = torch.zeros(2).to(DEV)
+    probe = torch.randn(2, 3, 64, 64, generator=g).to(DEV)
+
+    def grads():
+        return {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    for mod in net.modules():                       # BatchNorm buffers must not move between the two runs being compared
+        if hasattr(mod, "momentum"):
+            mod.momentum = 0.0
+    net.zero_grad(set_to_none=True)
+    (net(x, c, t, m) * probe).sum().backward()
+    g1 = grads()
+    net.zero_grad(set_to_none=True)
+    out = (net(x, c, t, m) * probe).sum()
+    try:
+        out.backward(retain_graph=True)
+        out.backward()
+    except (DmError, RuntimeError) as e:            # loud refusal is an accepted outcome
+        print("second backward refused:", str(e)[:120])
+        return
+    g2 = grads()
+    assert g1.keys() == g2.keys()
+    worst = max(((g2[k] - 2 * g1[k]).norm() / (2 * g1[k].norm() + 1e-20)).item() for k in g1 if g1[k].norm() > 1e-6)
+    print("two backward passes: worst relative deviation from 2 x one pass", worst)
+    assert worst <= 2e-3, worst
