@@ -369,7 +369,8 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvP p) {
 }
 
 int g_splitk_inkernel = 1;   // r03: on (the sc1 hand-off of igemm_dev.h costs no fence); 0: separate split-K epilogue launches
-int g_last_path = 0;  // kernel family the last dm_conv launch used: 0 = gather (conv_igemm*), 1 = conv3x3_halo_kernel
+int g_last_path = 0;  // kernel family the last dm_conv launch used: 0 = gather (conv_igemm*), 1 = conv3x3_halo_kernel, 3 = pointwise, 4 = packed-tap, 5 = narrow (<= 16 output channels)
+int g_packtap = 1;    // 8-channel inputs of 3x3 layers on conv3x3_packtap_kernel (igemm_skinny.hip)
 
 int g_variant = 5;    // 1 = register staging, 2..4 = LDS-DMA with that many ring stages (2 workgroups/CU at 2),
                       // 5 (default) = halo-resident kernel for eligible 3x3 layers, else LDS-DMA with 2 stages (4 on small grids)
@@ -476,6 +477,8 @@ int launch_conv(const ConvP& p, bool small_offsets, hipStream_t st) {
             if (m4 == 1) return launch_tap4_any(p, std::is_same<T, f16>::value, true, st);
             if (m4 == 2) return launch_tap4_any(p, std::is_same<T, f16>::value, false, st);
         }
+        if (g_variant == 5 && g_packtap && halo_eligible(p) && packtap_ok(p)) return launch_packtap_any(p, std::is_same<T, f16>::value, st);
+        if (g_variant == 5 && g_packtap && small_offsets && narrow_ok(p)) return launch_narrow_any(p, std::is_same<T, f16>::value, st);
         if (g_variant == 5 && halo_eligible(p)) return launch_halo_any(p, std::is_same<T, f16>::value, st);
     }
     const int mblocks = cdiv(p.M, BM);
@@ -540,6 +543,7 @@ extern "C" int dm_set_conv_variant(int variant) {
 }
 
 extern "C" int dm_last_conv_path(void) { return g_last_path; }
+extern "C" int dm_set_conv_packtap(int on) { g_packtap = on ? 1 : 0; return DM_OK; }
 extern "C" int dm_last_conv_persistent(void) { return dmk::g_last_persist; }
 extern "C" int dm_get_conv_variant(void) { return g_variant; }
 

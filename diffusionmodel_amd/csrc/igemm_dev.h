@@ -405,6 +405,11 @@ extern int g_conv_persist;           // igemm.hip: 1 = persistent halo kernel wh
 bool halo_persist_ok(const ConvP& p, int tiles, int ncu);                                  // igemm_halo_p.hip
 int launch_halo_persist_any(const ConvP& p, bool is_f16, int tiles, int ncu, hipStream_t st);
 int launch_tap4_any(const ConvP& p, bool is_f16, bool s2, hipStream_t st);                 // igemm_tap4.hip
+extern int g_packtap;                                                                      // igemm.hip
+bool packtap_ok(const ConvP& p);                                                           // igemm_skinny.hip
+int launch_packtap_any(const ConvP& p, bool is_f16, hipStream_t st);
+bool narrow_ok(const ConvP& p);
+int launch_narrow_any(const ConvP& p, bool is_f16, hipStream_t st);
 int launch_splitk_epilogue128(const ConvP& q, bool is_f16, unsigned grid, hipStream_t st);  // igemm.hip
 
 }  // namespace dmk

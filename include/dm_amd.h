@@ -78,8 +78,13 @@ int dm_conv_parity4(const DmConv* d4, dm_stream_t stream);
 int dm_set_conv_persist(int on);
 int dm_last_conv_persistent(void);   /* 1: the last dm_conv launch ran the persistent form */
 int dm_set_conv_variant(int variant);
-/* which kernel family the last dm_conv call launched: 0 = gather kernel (conv_igemm*), 1 = conv3x3_halo_kernel (profiling aid) */
+/* which kernel family the last dm_conv call launched: 0 = gather kernel (conv_igemm*), 1 = conv3x3_halo_kernel, 3 = pointwise,
+ * 4 = conv3x3_packtap_kernel, 5 = conv3x3_narrow_kernel (profiling aid) */
 int dm_last_conv_path(void);
+/* 1 (default): 3x3 stride-1 layers over an 8-channel input (the stem, new_scripy.py:381 -> :184; the head's input gradient, :314) run
+ * on the packed-tap kernel (igemm_skinny.hip: K = taps x 8 channels, 3 MFMA k-steps instead of 18), and 3x3 layers with <= 16 output
+ * channels (the head, :314) on the narrow halo kernel of the same file; 0: halo kernel's partial chunk / gather kernel */
+int dm_set_conv_packtap(int on);
 /* the value dm_set_conv_variant last set (default 5) */
 int dm_get_conv_variant(void);
 

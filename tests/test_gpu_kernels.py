@@ -1032,3 +1032,95 @@ def test_persistent_halo_kernel_exact_integers():
     (y.float() * nhwc(probe)).sum().backward()
     assert torch.equal(nchw(d1.grad), xr.grad)
     assert torch.equal(conv.weight.grad.cpu(), wr.grad)
+
+
+# ---- packed-tap kernel (igemm_skinny.hip): 3x3 layers over an 8-channel input — the stem and the head's input gradient -----------------
+@pytest.mark.parametrize("B,Co,H,dtype", [(3, 128, 64, torch.bfloat16), (2, 192, 64, torch.float16), (1, 128, 128, torch.bfloat16), (5, 40, 64, torch.bfloat16)])
+def test_packed_tap_kernel_stem_forward_exact_integers(B, Co, H, dtype):
+    """K = 9 taps x 8 channels packed into three MFMA k-steps (the fourth lane group of the last step multiplies zero weights with the
+    pixel of tap 8): integer data must reproduce F.conv2d bit for bit, image borders, column tiles (H = 128) and a ragged second
+    channel tile included; the weight gradient of the same layer still comes from the halo weight-gradient kernel."""
+    o = ops()
+    lib = __import__("diffusionmodel_amd")._lib.load()
+    g = torch.Generator().manual_seed(B * 7 + Co + H)
+    ri = lambda *s: torch.randint(-2, 3, s, generator=g).float()
+    x, w, b, probe = ri(B, 8, H, H), ri(Co, 8, 3, 3), ri(Co), torch.randint(-1, 2, (B, Co, H, H), generator=g).float()
+    probe = probe * (torch.rand(B, Co, H, H, generator=g) < 0.3).float()      # keeps the 8-channel input gradient below 256 (exact in bf16)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=1)
+    assert yr.abs().max() < 256
+    (yr * probe).sum().backward()
+    assert xr.grad.abs().max() < 256
+    conv = Holder(w, b)
+    d1 = nhwc(x, dtype).requires_grad_(True)
+    y = o.conv_bn_act(d1, None, conv, None, o.ConvSpec(3, 3, 1, 1))
+    assert lib.dm_last_conv_path() == 4                       # the forward launch took the packed-tap kernel
+    assert torch.equal(nchw(y), yr.detach())
+    (y.float() * nhwc(probe)).sum().backward()
+    assert torch.equal(nchw(d1.grad), xr.grad)                # (8 output channels: the gather kernel's 32-wide tiles)
+    assert torch.equal(conv.weight.grad.cpu(), wr.grad) and torch.equal(conv.bias.grad.cpu(), br.grad)
+
+
+@pytest.mark.parametrize("B,C,H,dtype", [(3, 128, 64, torch.bfloat16), (2, 256, 64, torch.float16), (1, 128, 128, torch.bfloat16)])
+def test_packed_tap_kernel_head_input_gradient_exact_integers(B, C, H, dtype):
+    """The head (C -> 3 channels): the forward runs on conv3x3_narrow_kernel (input halo and all nine taps of 16 output channels
+    resident, one image row per wave); its input gradient is a 3x3 convolution of the 8-channel (padded) output gradient with the
+    transposed weights and mirrored taps — the packed-tap kernel's FLIP form."""
+    o = ops()
+    lib = __import__("diffusionmodel_amd")._lib.load()
+    g = torch.Generator().manual_seed(B + C + H)
+    ri = lambda *s: torch.randint(-1, 2, s, generator=g).float()
+    x, w, b, probe = ri(B, C, H, H), ri(3, C, 3, 3), ri(3), ri(B, 3, H, H)
+    w = w * (torch.rand(3, C, 3, 3, generator=g) < 0.2).float()
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=1)
+    assert yr.abs().max() < 256
+    (yr * probe).sum().backward()
+    conv = Holder(w, b)
+    d1 = nhwc(x, dtype).requires_grad_(True)
+    y = o.conv_bn_act(d1, None, conv, None, o.ConvSpec(3, 3, 1, 1, out_nchw=True))      # the head's own call (modules.py: fp32 NCHW output)
+    assert lib.dm_last_conv_path() == 5                       # forward: the narrow halo kernel (<= 16 output channels)
+    assert torch.equal(y.float().cpu(), yr.detach())
+    (y.float() * probe.to(DEV)).sum().backward()
+    assert lib.dm_last_conv_path() == 4                       # the input-gradient launch (the only dm_conv of the backward pass)
+    assert torch.equal(nchw(d1.grad), xr.grad)
+    assert torch.equal(conv.weight.grad.cpu(), wr.grad) and torch.equal(conv.bias.grad.cpu(), br.grad)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_packed_tap_kernel_matches_the_halo_kernel_with_batchnorm_and_gelu(dtype):
+    """Train-mode stem (conv -> BatchNorm statistics in the epilogue -> GELU): same epilogue code as the halo kernel, another
+    accumulation order in the k loop — outputs, running statistics and all gradients agree to rounding."""
+    o = ops()
+    from diffusionmodel_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(21)
+    B, H, N = 6, 64, 128
+    x = torch.randn(B, H, H, 8).to(dtype).to(DEV)
+    x[..., 3:] = 0                                              # (the stem's five padding channels)
+    w = torch.nn.Parameter((torch.randn(N, 8, 3, 3) / math.sqrt(27)).to(DEV).contiguous(memory_format=torch.channels_last))
+    bias = torch.nn.Parameter(torch.randn(N).to(DEV) * 0.1)
+    probe = torch.randn(B, H, H, N).to(dtype).to(DEV)
+    bn = torch.nn.BatchNorm2d(N).to(DEV).train()
+    sd = {k: v.clone() for k, v in bn.state_dict().items()}
+
+    def run(on):
+        lib.dm_set_conv_packtap(on)
+        bn.load_state_dict(sd)
+        w.grad = bias.grad = bn.weight.grad = bn.bias.grad = None
+        conv = Holder.__new__(Holder)
+        conv.weight, conv.bias = w, bias
+        y = o.conv_bn_act(x, None, conv, bn, o.ConvSpec(3, 3, 1, 1, o.ACT_GELU, bn))
+        path = lib.dm_last_conv_path()
+        (y.float() * probe.float()).sum().backward()
+        return [y.detach().float(), w.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(), bn.running_var.clone()], path
+    try:
+        a, pa = run(1)
+        b_, pb = run(0)
+    finally:
+        lib.dm_set_conv_packtap(1)
+    assert pa == 4 and pb == 1, (pa, pb)
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    for name, u, v in zip(("y", "dw", "dgamma", "dbeta", "running_mean", "running_var"), a, b_):
+        tol = 2 * ulp if name == "y" else 2e-3
+        assert float((u - v).abs().max()) <= tol * float(v.abs().max()), (name, float((u - v).abs().max()), float(v.abs().max()))
