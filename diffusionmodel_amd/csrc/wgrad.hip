@@ -864,6 +864,234 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restri
         if (n + r < N && chunk * 64 + (wave >> 1) * 16 + (lane & 15) < C) o[(size_t)r * ldw] += s[r];
 }
 
+// =================================================================================================
+// wgrad3x3_skinny_kernel: weight gradient of the 3x3 stride-1 layers with 8 (padded) channels on ONE side — the stem (3 -> F,
+// new_scripy.py:381 -> :184) and the head (F -> 3, :314) — at full resolution
+// =================================================================================================
+// dw[n][tap][c] = sum over pixels of dy[p][n] * x[p + tap][c].  The halo kernel above gives the 8-channel side a 64- (input) or
+// 128-wide (output) tile of zeros.  Here the WIDE side (128 channels: dy for the stem, x for the head) is the MFMA's row operand,
+// unshifted, and the NARROW side's 8 channels x 9 taps are PACKED into the column operand: a transposed read delivers 4 pixels x 16
+// columns from four 8-byte pieces per pixel row, and a lane's address may point each piece anywhere — columns 0..7 at the narrow
+// pixel shifted by tap 2 jt, columns 8..15 at tap 2 jt + 1.  D[wide 128][(tap, narrow) 72 of 80] per k-step of 32 pixels: 20 MFMAs
+// per wave instead of 144.  SWAP = false (stem): narrow = x shifted by +tap, dw[n = wide][tap][c = narrow], and the spare column 72
+// reads a constant-one pixel, i.e. it is dbias.  SWAP = true (head): narrow = dy shifted by -tap, dw[n = narrow][tap][c = wide]; dbias
+// = column sums of the narrow tile (wave 7).
+//   * tile = 2 image rows x 64 columns (128 pixels); 8 waves = 2 (wide halves of 64 channels) x 4 (k-steps of the tile): every wave
+//     owns ONE k-step of every tile, so all fragment addresses are per-lane constants.
+//   * wide image: the dy image of the kernel above (256-B rows, 32-B chunk ch at ch ^ (row & 7)); narrow image: 4 x 72 pixels x 16 B,
+//     linear, out-of-image pixels zero (DMA range check); two stages, one barrier per tile.
+//   * the four k-step waves fold through LDS at the end; the two remaining register images go to the workspace and
+//     wgrad_skinny_reduce_kernel adds the workgroups' partials into dw / dbias.
+constexpr int WGS_WIDE = 128 * 256;                        // wide image of a stage
+constexpr int WGS_NARROW = 5 * 1024;                       // 4 x 72 x 16 B = 4608 B, filled as 5 pieces
+constexpr int WGS_STAGE = WGS_WIDE + WGS_NARROW;
+constexpr int WGS_LDS = 2 * WGS_STAGE + 64;                // + the constant-one pixel
+
+// One LDS-DMA piece (64 lanes x 16 B -> 1 KiB at `lds`) as inline asm.  hipcc orders every ds_read_tr INTRINSIC after all LDS-DMA it
+// knows to be pending (s_waitcnt vmcnt(0) before the first transposed read that follows an issue), which would serialise this
+// kernel's two stages; it does not see these.  M0 = LDS base, one wait state before the DMA reads it; no other user of M0 here.
+__device__ __forceinline__ void wgs_dma16(__amdgpu_buffer_rsrc_t r, char* lds, unsigned voff, int soff) {
+    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_dst3)lds);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(la), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+
+struct WgSP {
+    const char* wide; const char* narrow; float* dw; float* dbias; float* ws;
+    int B, Hi, Wi, CW, ldwide, N, ldw, C;                  // CW: channels of the wide tensor; N / C: the layer's output / input channels
+    int ntiles, tiles_per_wg, nblk;                        // nblk: 128-channel blocks of the wide side
+};
+
+template <typename T, bool SWAP>
+__global__ __launch_bounds__(512) void wgrad3x3_skinny_kernel(const WgSP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wh = wave & 1, wq = wave >> 1;               // wide half, k-step of the tile
+    const int g = lane >> 4, il = lane & 15, q = il >> 2, pp = il & 3;
+    const int blk = blockIdx.x % p.nblk, wgi = blockIdx.x / p.nblk;
+    const int c0 = blk * 128;
+    const int t_lo = wgi * p.tiles_per_wg, t_hi = min(t_lo + p.tiles_per_wg, p.ntiles);
+    const int tcols = p.Wi >> 6, tiles_img = (p.Hi >> 1) * tcols;
+
+    const __amdgpu_buffer_rsrc_t rWd = __builtin_amdgcn_make_buffer_rsrc((void*)p.wide, 0, p.ntiles * 128 * p.ldwide * 2, WG_SRD);
+    const __amdgpu_buffer_rsrc_t rNr = __builtin_amdgcn_make_buffer_rsrc((void*)p.narrow, 0, p.ntiles * 128 * 16, WG_SRD);
+    if (tid < 8) ((unsigned short*)(smem + 2 * WGS_STAGE))[tid] = tid == 0 ? (std::is_same<T, f16>::value ? 0x3C00 : 0x3F80) : 0;     // 1.0 in the tensor type
+    __syncthreads();
+
+    // ---- staging constants: wide pieces 8 j + wave (4 pixel rows x 256 B), narrow piece `wave` (waves 0..4, 64 pixels x 16 B)
+    unsigned wdv;
+    {
+        const int row = wave * 4 + (lane >> 4), s_ = lane & 15;
+        const int lslot = ((((s_ >> 1) ^ (row & 7)) << 1) | (s_ & 1));
+        const int col = c0 + lslot * 8;
+        wdv = col + 8 <= p.CW ? (unsigned)(((lane >> 4) * p.ldwide + col) * 2) : WG_OOB;     // + the piece's first pixel row as a scalar offset
+    }
+    const int nhp = wave * 64 + lane, nhy = nhp / 72, nhx = nhp - nhy * 72;
+    auto issue = [&](int stage, int tile) {
+        char* sA = smem + stage * WGS_STAGE;
+        const int bimg = tile / tiles_img, trem = tile - bimg * tiles_img;
+        const int y0 = (trem / tcols) * 2, x0 = (trem % tcols) * 64;
+        const int pix0 = (bimg * p.Hi + y0) * p.Wi + x0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                      // pieces 8 j + wave: tile pixels 4 (8 j + wave) .. + 3 — (part of) one image row
+            const int tp = (8 * j + wave) * 4;              // first tile pixel of the piece: row tp >> 6 of the tile, column tp & 63
+            const int prow = pix0 + (tp >> 6) * p.Wi + (tp & 63);
+            wgs_dma16(rWd, sA + (j * 8 + wave) * 1024, wdv, prow * p.ldwide * 2);
+        }
+        if (wave < 5) {
+            const int y = y0 + nhy - 1, x = x0 + nhx - 1;
+            const bool ok = nhy < 4 && nhx < 66 && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+            const unsigned v = ok ? (unsigned)(((bimg * p.Hi + y) * p.Wi + x) * 16) : WG_OOB;
+            wgs_dma16(rNr, sA + WGS_WIDE + wave * 1024, v, 0);
+        }
+    };
+
+    // ---- fragment addresses (this wave's k-step wq: tile pixels 32 wq .. 32 wq + 31 = tile row wq >> 1, columns 32 (wq & 1) ..)
+    int addrA[4], addrB[5];
+    {
+        const int row = 4 * g + q;                          // pixel of the k-step (the second half of a pair: + 16)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) addrA[it] = (wq * 32 + row) * 256 + (((wh * 4 + it) ^ (row & 7)) << 5) + 8 * pp;
+#pragma unroll
+        for (int jt = 0; jt < 5; ++jt) {
+            const int t = 2 * jt + (pp >> 1), tt = t < 9 ? t : 8;
+            const int sy = SWAP ? 1 - tt / 3 : tt / 3 - 1, sx = SWAP ? 1 - tt % 3 : tt % 3 - 1;
+            const int hp = (1 + (wq >> 1) + sy) * 72 + 1 + (wq & 1) * 32 + row + sx;
+            addrB[jt] = WGS_WIDE + hp * 16 + (pp & 1) * 8;
+        }
+    }
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    auto tr_pair = [&](const char* a, int hi) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a));
+        const s16x4 h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a + hi));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], h[0], h[1], h[2], h[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    // stem: the spare taps of column tile 4 (t = 9) read the constant-one pixel: column 72 accumulates sum(dy) = dbias
+    const bool ones = !SWAP && (pp >> 1) == 1;
+
+    f32x4 acc[4][5];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // head: column sums of the narrow tile (wave 7)
+
+    if (t_lo < t_hi) issue(0, t_lo);
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+        const int cur = (tile - t_lo) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tile + 1 < t_hi) issue(cur ^ 1, tile + 1);
+        const char* sS = smem + cur * WGS_STAGE;
+        bf16x8 fa[4], fb[5];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) fa[it] = tr_pair(sS + addrA[it], 16 * 256);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) fb[jt] = tr_pair(sS + addrB[jt], 16 * 16);
+        fb[4] = tr_pair(ones ? smem + 2 * WGS_STAGE + (pp & 1) * 8 : sS + addrB[4], ones ? 0 : 16 * 16);      // (address select: every lane takes part in the read)
+#pragma unroll
+        for (int jt = 0; jt < 5; ++jt)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) acc[it][jt] = WMma<T>::run(fa[it], fb[jt], acc[it][jt]);
+        if (SWAP && p.dbias != nullptr && wave == 7 && blk == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                   // tile pixels lane, lane + 64: narrow rows 1, 2, columns 1 .. 64
+                const typename V16<T>::x8 v = *(const typename V16<T>::x8*)(sS + WGS_WIDE + ((1 + h) * 72 + 1 + lane) * 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum[e] += (float)v[e];
+            }
+        }
+    }
+
+    // ---- fold the four k-step waves of each wide half (k-steps 1..3 into 0), then park the register images
+    __syncthreads();
+    f32x4* fold = (f32x4*)smem;                            // [wh][20][64] f32x4 = 40 KiB
+#pragma unroll 1
+    for (int r = 1; r < 4; ++r) {
+        if (wq == r) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 5; ++jt) fold[(wh * 20 + it * 5 + jt) * 64 + lane] = acc[it][jt];
+        }
+        __syncthreads();
+        if (wq == 0) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 5; ++jt) {
+                    const f32x4 v = fold[(wh * 20 + it * 5 + jt) * 64 + lane];
+                    acc[it][jt] += v;
+                }
+        }
+        __syncthreads();
+    }
+    if (wq == 0) {
+        f32x4* dst = (f32x4*)p.ws + ((size_t)blockIdx.x * 2 + wh) * 20 * 64 + lane;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 5; ++jt) dst[(it * 5 + jt) * 64] = acc[it][jt];
+    }
+    if (SWAP && p.dbias != nullptr && wave == 7 && blk == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = bsum[e];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            // parked next to the images: the reduce kernel folds the workgroups' sums in a fixed order
+            if (lane == 0) p.ws[(size_t)gridDim.x * 10240 + wgi * 8 + e] = v;
+        }
+    }
+}
+
+// dw (+ dbias for the stem) += sum over the workgroups' register images: element (wh, it, jt, lane, r) is row i = 64 wh + 16 it +
+// 4 (lane >> 4) + r of the wide block, column j = 16 jt + (lane & 15)
+template <bool SWAP>
+__global__ __launch_bounds__(256) void wgrad_skinny_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ dbias,
+                                                                 int nwg, int nblk, int N, int C, int ldw) {
+    const int e = blockIdx.x * 256 + threadIdx.x;          // float index within a (block, workgroup) image: 2 * 20 * 64 * 4 = 10240
+    const int blk = blockIdx.y;
+    if (SWAP && dbias != nullptr && blockIdx.x == 0 && blk == 0 && blockIdx.z == 0) {    // head: the workgroups' column sums of dy, a wave per channel
+        const int lane = threadIdx.x & 63;
+        for (int n = threadIdx.x >> 6; n < N; n += 4) {
+            float b = 0.f;
+            for (int w = lane; w < nwg; w += 64) b += ws[(size_t)nwg * nblk * 10240 + w * 8 + n];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o, 64);
+            if (lane == 0) dbias[n] += b;
+        }
+    }
+    if (e >= 10240) return;
+    // gridDim.z slices of the workgroup list, eight independent loads in flight per thread; the slices meet in dw through atomics
+    const int per = (nwg + gridDim.z - 1) / gridDim.z, w0 = blockIdx.z * per, w1 = min(w0 + per, nwg);
+    float s = 0.f;
+    int w = w0;
+    for (; w + 8 <= w1; w += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = ws[((size_t)((w + k) * nblk + blk)) * 10240 + e];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; w < w1; ++w) s += ws[((size_t)(w * nblk + blk)) * 10240 + e];
+    if (w0 >= w1) return;
+    const int r = e & 3, lane = (e >> 2) & 63, tile = (e >> 8) % 20, wh = e / (20 * 256);
+    const int it = tile / 5, jt = tile - it * 5;
+    const int i = blk * 128 + wh * 64 + it * 16 + 4 * (lane >> 4) + r, j = jt * 16 + (lane & 15);
+    if (SWAP) {
+        const int t = j >> 3, n = j & 7;
+        if (j < 72 && n < N && i < C) atomicAdd(dw + (size_t)n * ldw + t * C + i, s);
+    } else {
+        if (i >= N) return;
+        if (j < 72) { if ((j & 7) < C) atomicAdd(dw + (size_t)i * ldw + (j >> 3) * C + (j & 7), s); }
+        else if (j == 72 && dbias != nullptr) atomicAdd(dbias + i, s);
+    }
+}
+
+int g_wgrad_skinny = 1;
 int g_wgrad_halo = 1;
 
 int g_wgrad_variant = 2;
@@ -1011,6 +1239,55 @@ bool wgrad_halo_plan(const DmWgrad* d, int64_t M, WgHP& hp) {
     return true;
 }
 
+// 3x3 stride-1 pad-1 layer at full resolution (rows a multiple of 64 pixels, an even number of them) with 8 channels on one side
+// and whole 128-channel blocks on the other: 1 = stem form (8 input channels), 2 = head form (<= 8 output channels, ldy == 8)
+int wgrad_skinny_plan(const DmWgrad* d, int64_t M, WgSP& sp) {
+    if (!g_wgrad_skinny || !g_wgrad_halo || d->dtype == DM_F32 || d->T != 9 || d->KW != 3 || d->sy != 1 || d->sx != 1) return 0;
+    if (d->ty != 1 || d->tx != 1 || d->oy0 != -1 || d->ox0 != -1 || d->C2 != 0 || d->splitk > 0) return 0;
+    if (d->Hq != d->Hi || d->Wq != d->Wi || d->Ho != d->Hq || d->Wo != d->Wq || d->osy != 1 || d->osx != 1 || d->ooy != 0 || d->oox != 0) return 0;
+    if (d->Wi < 64 || d->Wi % 64 != 0 || d->Hi % 2 != 0) return 0;
+    if (((uintptr_t)d->dy & 15) || ((uintptr_t)d->in1 & 15) || dm_g_ws == nullptr) return 0;
+    int form = 0;
+    if (d->C1 == 8 && d->N % 128 == 0 && d->ldy == d->N && d->ldw == 72) form = 1;
+    else if (d->N <= 8 && d->ldy == 8 && d->C1 % 128 == 0 && d->ldw == 9 * d->C1) form = 2;
+    if (form == 0) return 0;
+    const int CW = form == 1 ? d->N : d->C1;
+    if (M * CW * 2 >= (1ll << 31)) return 0;
+    sp.wide = (const char*)(form == 1 ? d->dy : d->in1);
+    sp.narrow = (const char*)(form == 1 ? d->in1 : d->dy);
+    sp.dw = d->dw; sp.dbias = d->dbias; sp.ws = dm_g_ws;
+    sp.B = d->B; sp.Hi = d->Hi; sp.Wi = d->Wi; sp.CW = CW; sp.ldwide = CW; sp.N = d->N; sp.ldw = d->ldw; sp.C = d->C1;
+    sp.ntiles = (int)(M / 128);
+    sp.nblk = CW / 128;
+    int wgs = 256 / sp.nblk;                                // one workgroup per CU
+    if (wgs < 1) wgs = 1;
+    if (wgs > sp.ntiles) wgs = sp.ntiles;
+    sp.tiles_per_wg = cdiv(sp.ntiles, wgs);
+    const int nwg = cdiv(sp.ntiles, sp.tiles_per_wg);
+    if (((int64_t)nwg * sp.nblk * 10240 + nwg * 8) * 4 > dm_g_ws_bytes) return 0;
+    return form;
+}
+
+template <typename T, bool SWAP>
+int launch_wgrad_skinny_t(const WgSP& p, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_skinny_kernel<T, SWAP>, hipFuncAttributeMaxDynamicSharedMemorySize, WGS_LDS);
+        if (e != hipSuccess) { dm_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", WGS_LDS, hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    const int nwg = cdiv(p.ntiles, p.tiles_per_wg);
+    hipLaunchKernelGGL((wgrad3x3_skinny_kernel<T, SWAP>), dim3((unsigned)(nwg * p.nblk)), dim3(512), WGS_LDS, st, p);
+    DM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad_skinny_reduce_kernel<SWAP>, dim3(40, (unsigned)p.nblk, 16), dim3(256), 0, st, (const float*)p.ws, p.dw, p.dbias, nwg, p.nblk, p.N, p.C, p.ldw);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+int launch_wgrad_skinny(const WgSP& p, bool swap, bool is_f16, hipStream_t st) {
+    if (is_f16) return swap ? launch_wgrad_skinny_t<f16, true>(p, st) : launch_wgrad_skinny_t<f16, false>(p, st);
+    return swap ? launch_wgrad_skinny_t<bf16, true>(p, st) : launch_wgrad_skinny_t<bf16, false>(p, st);
+}
+
 int g_wgrad_pw = 1;            // 1x1 layers on wgrad_pw_kernel
 int g_wgrad_pw_blocks = 384;   // workgroups its pixel split aims at when a workgroup's block is 4096 floats; fewer for larger blocks (same atomic traffic)
 int g_wgrad_pw_min_m = 0;      // pixels below which the per-tap kernel keeps the launch
@@ -1062,6 +1339,7 @@ int launch_wgrad_pw(const WgPwP& q, int ntw, int ctw, hipStream_t st) {
 
 static int g_last_wgrad_path = 0;   // 1: the last dm_conv_wgrad launch went to wgrad3x3_halo_kernel, 2: to wgrad_pw_kernel, 3: to the four-tap (S2) form of 1
 extern "C" int dm_last_wgrad_path(void) { return g_last_wgrad_path; }
+extern "C" int dm_set_wgrad_skinny(int on) { g_wgrad_skinny = on ? 1 : 0; return DM_OK; }
 
 extern "C" int dm_set_wgrad_tap4(int on) {      // on > 1 also sets the workgroup target
     g_wgrad_tap4 = on != 0;
@@ -1102,6 +1380,14 @@ extern "C" int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream) {
     DM_CHECK_ARG((int64_t)d->T * cdiv(d->C1 + d->C2, 128) < 65536, "dm_conv_wgrad: grid.y too large");
     WgHP hp;
     g_last_wgrad_path = 0;
+    {
+        WgSP sp;
+        const int sk = wgrad_skinny_plan(d, M, sp);         // 1: stem form, 2: head form
+        if (sk != 0) {
+            g_last_wgrad_path = 4;
+            return launch_wgrad_skinny(sp, sk == 2, d->dtype == DM_F16, (hipStream_t)stream);
+        }
+    }
     if (wgrad_halo_plan(d, M, hp)) {
         g_last_wgrad_path = 1;
         hipStream_t hst = (hipStream_t)stream;

@@ -195,7 +195,7 @@ class DDPM(_HipBlock):
             one_step(None)                                            # warm-up: fills packed-weight / BN-fold caches
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):      # (the RCCL watchdog thread may poll events meanwhile)
                 one_step(None)
             for _ in range(n_iter - 1):
                 g.replay()

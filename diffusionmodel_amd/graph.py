@@ -121,7 +121,8 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph(keep_graph=True) if mode == "plan" else torch.cuda.CUDAGraph()
         ops.PROFILE_META = meta = []               # (kernel family, algorithmic FLOPs, shape) of every MFMA launch, in launch order
         try:
-            with torch.cuda.graph(self.graph):
+            # thread_local: other threads of the process (the RCCL watchdog polls its events) may keep calling the runtime during the capture
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.loss = self._eager()
         finally:
             ops.PROFILE_META = None

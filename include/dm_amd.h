@@ -107,7 +107,10 @@ int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream);
 int dm_set_wgrad_variant(int variant);
 /* 1 when the last dm_conv_wgrad launch used the halo-resident 3x3 kernel, 2 for the 1x1 kernel (wgrad_pw_kernel), 3 for the four-tap form of the halo kernel (4x4 / stride 2), 0 for the per-tap
    kernels (measurement aid) */
-int dm_last_wgrad_path(void);
+int dm_last_wgrad_path(void);   /* 4: wgrad3x3_skinny_kernel (below) */
+/* on != 0 (default): the weight gradient of the full-resolution 3x3 layers with 8 (padded) channels on one side — the stem (new_scripy.py:381
+   -> :184) and the head (:314) — on wgrad3x3_skinny_kernel (taps x 8 channels packed into the MFMA's column operand); 0: halo kernel */
+int dm_set_wgrad_skinny(int on);
 /* on != 0 (default): the weight gradient of the 16-bit 4x4 / stride-2 / pad-1 layers (output rows of 32 / 16 pixels or 8x8 output
    images) on the four-tap form of the halo-resident kernel; 0: per-tap kernel; > 1: also the workgroup count its pixel split aims at
    (default 256).  dm_last_wgrad_path() reports 3.  Measurement knob. */

@@ -1058,6 +1058,7 @@ def test_packed_tap_kernel_stem_forward_exact_integers(B, Co, H, dtype):
     assert torch.equal(nchw(y), yr.detach())
     (y.float() * nhwc(probe)).sum().backward()
     assert torch.equal(nchw(d1.grad), xr.grad)                # (8 output channels: the gather kernel's 32-wide tiles)
+    assert lib.dm_last_wgrad_path() == (4 if Co % 128 == 0 else 1)      # whole 128-channel blocks: wgrad3x3_skinny_kernel (stem form)
     assert torch.equal(conv.weight.grad.cpu(), wr.grad) and torch.equal(conv.bias.grad.cpu(), br.grad)
 
 
@@ -1083,6 +1084,7 @@ def test_packed_tap_kernel_head_input_gradient_exact_integers(B, C, H, dtype):
     assert torch.equal(y.float().cpu(), yr.detach())
     (y.float() * probe.to(DEV)).sum().backward()
     assert lib.dm_last_conv_path() == 4                       # the input-gradient launch (the only dm_conv of the backward pass)
+    assert lib.dm_last_wgrad_path() == 4                      # wgrad3x3_skinny_kernel (head form: dy is the 8-channel side)
     assert torch.equal(nchw(d1.grad), xr.grad)
     assert torch.equal(conv.weight.grad.cpu(), wr.grad) and torch.equal(conv.bias.grad.cpu(), br.grad)
 
