@@ -217,8 +217,9 @@ def cpu_baseline(args):
 
 
 FAMILIES = (   # (family, substrings of kernel names) — first match wins
-    ("conv", ("conv3x3_halo_kernel", "conv3x3_halo_pkernel", "conv_tap4_halo_kernel", "conv_pw_kernel", "conv_igemm", "splitk_epilogue")),
-    ("wgrad", ("wgrad3x3_halo_kernel", "wgrad_reduce", "wgrad_pw_kernel", "conv_wgrad")),
+    ("conv", ("conv3x3_halo_kernel", "conv3x3_halo_pkernel", "conv3x3_packtap_kernel", "conv3x3_narrow_kernel", "conv_tap4_halo_kernel", "conv_pw_kernel",
+              "conv_igemm", "splitk_epilogue")),
+    ("wgrad", ("wgrad3x3_halo_kernel", "wgrad3x3_skinny_kernel", "wgrad_skinny_reduce", "wgrad_reduce", "wgrad_pw_kernel", "conv_wgrad")),
     ("batchnorm", ("bn_act_fwd", "bn_bwd_reduce", "bn_bwd_apply", "bn_finalize", "col_reduce", "col_stats")),
     ("optimiser", ("adamw", "sumsq", "pack_multi", "scatter_copy", "scaler_update", "pack_w")),
     ("attention", ("se_fwd", "se_bwd", "ca_z_", "ca_mix", "ca_bwd", "ca_gate", "ca_pix", "strip_reduce", "strip_fold", "scale_res", "dense_", "sgemm",

@@ -19,7 +19,7 @@ for r in rows:
     a = fam.setdefault(f, [0.0, 0.0])
     a[0] += ms; a[1] += n
     key = r["Name"].split("(")[0][:60]
-    for k in ("conv3x3_halo_pkernel", "conv3x3_halo_kernel", "conv_tap4_halo", "conv_pw_kernel", "conv_igemm2", "splitk_epilogue", "wgrad3x3_halo", "wgrad_reduce",
+    for k in ("conv3x3_halo_pkernel", "conv3x3_halo_kernel", "conv3x3_packtap", "conv3x3_narrow", "conv_tap4_halo", "conv_pw_kernel", "conv_igemm2", "splitk_epilogue", "wgrad3x3_halo", "wgrad3x3_skinny", "wgrad_skinny_reduce", "wgrad_reduce",
               "wgrad_pw", "conv_wgrad2", "bn_bwd_apply", "bn_bwd_reduce", "bn_act_fwd", "adamw", "sumsq", "pack_multi", "se_fwd", "se_bwd", "ca_z_", "ca_mix",
               "ca_bwd_mix", "ca_bwd_z", "strip_reduce", "scale_res", "ca_pix", "ca_gate", "dense_", "upcat", "gn_", "film"):
         if k in r["Name"]:
