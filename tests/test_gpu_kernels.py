@@ -1035,7 +1035,8 @@ def test_persistent_halo_kernel_exact_integers():
 
 
 # ---- packed-tap kernel (igemm_skinny.hip): 3x3 layers over an 8-channel input — the stem and the head's input gradient -----------------
-@pytest.mark.parametrize("B,Co,H,dtype", [(3, 128, 64, torch.bfloat16), (2, 192, 64, torch.float16), (1, 128, 128, torch.bfloat16), (5, 40, 64, torch.bfloat16)])
+@pytest.mark.parametrize("B,Co,H,dtype", [(3, 128, 64, torch.bfloat16), (2, 192, 64, torch.float16), (1, 128, 128, torch.bfloat16), (5, 40, 64, torch.bfloat16),
+                                          (2, 256, 64, torch.bfloat16)])      # (256: two channel tiles / two wide blocks, the cfg-5 stem)
 def test_packed_tap_kernel_stem_forward_exact_integers(B, Co, H, dtype):
     """K = 9 taps x 8 channels packed into three MFMA k-steps (the fourth lane group of the last step multiplies zero weights with the
     pixel of tap 8): integer data must reproduce F.conv2d bit for bit, image borders, column tiles (H = 128) and a ragged second
