@@ -37,6 +37,7 @@
 // the 8 XCDs, so tile = (bid % 8) * (ntiles / 8) + bid / 8 (bijective form) gives every XCD a contiguous
 // run of tiles — vertically adjacent image rows (shared 3x3 halo) and the n-tiles of one pixel block
 // then meet in the same 4 MiB L2.  Placement only affects speed, never results.
+#include <cstdlib>
 #include "igemm_dev.h"
 
 namespace dmk {
@@ -485,7 +486,15 @@ int launch_conv(const ConvP& p, bool small_offsets, hipStream_t st) {
     int bn = 128;
     if (p.N <= 32) bn = 32;
     else if (p.N <= 64) bn = 64;
-    else if ((int64_t)mblocks * cdiv(p.N, 128) < 256) bn = 64;  // small problems: more, smaller tiles
+    else if ((int64_t)mblocks * cdiv(p.N, 128) < 256) {            // small problems: more, smaller tiles ...
+        bn = 64;
+        // ... unless the reduction is deep enough for split-K to fill the chip with 128-wide tiles (the 4x4 / stride-2 layer on 8x8
+        // maps, K = 16 x 1024): the fill per MFMA is what bounds this kernel, and a 128 x 128 tile needs 1.5x less of it
+        static const int deep = getenv("DM_DEEP_BN128") ? atoi(getenv("DM_DEEP_BN128")) : 1;   // (0: A/B measurements; 97 -> 73 us on that layer)
+        const int64_t t128 = (int64_t)mblocks * cdiv(p.N, 128);
+        const int ks = p.T * cdiv(p.C1 + p.C2, 128 / (int)sizeof(T));
+        if (deep && small_offsets && t128 <= 128 && dm_g_ws != nullptr && ks / 4 >= 256 / t128 && (256 / t128) * t128 >= 192) bn = 128;
+    }
     const int64_t tiles = (int64_t)mblocks * cdiv(p.N, bn);
     int variant = small_offsets ? g_variant : 1;
     // fewer workgroups than CUs: nothing else hides the load latency, so run the ring 3 steps ahead instead of 1

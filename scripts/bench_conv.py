@@ -21,6 +21,7 @@ SHAPES = [  # (name, B, H, Cin, Cout, k, stride)
     ("8^2 1024->1024 3x3", 64, 8, 1024, 1024, 3, 1),
     ("8^2 2048->512 3x3", 64, 8, 2048, 512, 3, 1),
     ("64^2 128->128 4x4s2", 64, 64, 128, 128, 4, 2),
+    ("8^2 1024->1024 4x4s2", 64, 8, 1024, 1024, 4, 2),
     ("64^2 128->32 1x1", 64, 64, 128, 32, 1, 1),
     ("64^2 32->128 1x1", 64, 64, 32, 128, 1, 1),
     ("128^2 256->256 3x3 (cfg-5)", 8, 128, 256, 256, 3, 1),
