@@ -18,6 +18,7 @@
 // Grid: x = 128-wide n tiles, y = taps x 128-wide c tiles, z = split over pixels (fp32 atomics
 // combine the splits — and accumulate into whatever dw already holds, which is how gradient
 // accumulation over micro-batches comes for free).  Blocks with y == 0 also produce dbias.
+#include <cstdlib>
 #include "common.h"
 // Where the halo weight-gradient kernel issues the next tile's LDS-DMA pieces: 0 = all right after the tile's barrier; 0xAABB = the dy
 // pieces at slot AA, the halo pieces at slot BB, slot = 16 k-step + tap (issued before that tap's MFMAs).
@@ -32,6 +33,7 @@ struct WgP {
     int B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0;
     int Ho, Wo, osy, osx, ooy, oox, N, ldy, ldw, M, csteps_c, steps_per_split, total_steps;
     int gx, gy, gz;   // logical grid of the v2 kernel (launched 1-D, see the XCD mapping there)
+    int rmw;          // v2: 1 = no pixel split -> plain read-modify-write of dw instead of atomics
 };
 
 template <typename T> struct WgCfg;
@@ -384,18 +386,37 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgP p) {
     }
 
     const int g = lane >> 4, il = lane & 15;
+    if (p.rmw) {
+        // no pixel split (the two 16.7 M-parameter layers of the bottleneck: 1024 tiles already): this workgroup is the only writer
+        // of its dw elements within the launch — plain read-modify-write instead of 16.7 M fp32 atomics
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
+        for (int it = 0; it < 4; ++it)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + wn * 64 + it * 16 + 4 * g + r;
-            if (n >= p.N) continue;
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + it * 16 + 4 * g + r;
+                if (n >= p.N) continue;
+                float* row = p.dw + (size_t)n * p.ldw + (size_t)t * C + c0 + wc * 64 + il;
+                float old[4];
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                const int c = c0 + wc * 64 + jt * 16 + il;
-                if (c < C) atomicAdd(p.dw + (size_t)n * p.ldw + (size_t)t * C + c, acc[it][jt][r]);
+                for (int jt = 0; jt < 4; ++jt) old[jt] = c0 + wc * 64 + jt * 16 + il < C ? row[jt * 16] : 0.f;
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+                    if (c0 + wc * 64 + jt * 16 + il < C) row[jt * 16] = old[jt] + acc[it][jt][r];
             }
-        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + it * 16 + 4 * g + r;
+                if (n >= p.N) continue;
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    const int c = c0 + wc * 64 + jt * 16 + il;
+                    if (c < C) atomicAdd(p.dw + (size_t)n * p.ldw + (size_t)t * C + c, acc[it][jt][r]);
+                }
+            }
+    }
     if (do_bias && n0 + tid < p.N) atomicAdd(p.dbias + n0 + tid, bias_acc);
 }
 
@@ -1125,6 +1146,8 @@ int launch_wgrad(WgP& p, int splitk_req, bool v2_ok, hipStream_t st) {
             attr_set = true;
         }
         p.gx = grid.x; p.gy = grid.y; p.gz = grid.z;
+        static const int rmw_on = getenv("DM_WGRAD_RMW") ? atoi(getenv("DM_WGRAD_RMW")) : 1;     // (0: A/B measurements)
+        p.rmw = rmw_on && grid.z == 1;
         const unsigned total = grid.x * grid.y * (grid.z >= 8 ? (grid.z + 7) / 8 * 8 : grid.z);
         hipLaunchKernelGGL((conv_wgrad2_kernel<T>), dim3(total), dim3(256), bytes, st, p);
     } else {
