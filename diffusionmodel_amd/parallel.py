@@ -153,7 +153,13 @@ class OverlappedGradReducer:
         self.opt, self.group, self._ops = opt, group, ops
         self.flat = opt.flat_g
         self.active = dist.is_initialized()
-        self._stream = torch.cuda.Stream() if self.flat.is_cuda else None
+        # RCCL runs a collective on the process group's OWN stream (ordered after the issuing stream by an event, waited for by
+        # Work.wait()): a second stream of ours in front of it is one more queue hand-off per bucket for nothing (DESIGN section 6:
+        # the first cross-queue leg of a step costs ~0.3 ms whatever travels on it).  Other backends (gloo on device tensors: the
+        # rehearsal tests) block the issuing stream, so they keep the side stream.  DM_DP_SIDE_STREAM=1/0 overrides.
+        side = os.environ.get("DM_DP_SIDE_STREAM")
+        use_side = (not self.active or dist.get_backend(group) != "nccl") if side is None else side != "0"
+        self._stream = torch.cuda.Stream() if (self.flat.is_cuda and use_side) else None
         # RCCL orders a collective after the work already queued on the stream it is issued from; gloo stages device tensors
         # through the host on its own schedule, so with gloo (rehearsals on one GPU) the device is drained before every launch
         self._drain = self.active and self.flat.is_cuda and dist.get_backend(group) != "nccl"
@@ -231,6 +237,8 @@ class OverlappedGradReducer:
             with torch.cuda.stream(self._stream):
                 self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
+            if _NOCOMM and self.flat.is_cuda:
+                return
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _copy_small(self, to_packed):

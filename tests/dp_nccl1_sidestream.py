@@ -59,13 +59,18 @@ side_launches = [0]
 _plain_launch = red._launch
 
 
+load_stream = red._stream if red._stream is not None else torch.cuda.Stream()
+
+
 def _loaded_launch(b):
-    """The reducer's bucket launch + a streaming load behind it on the SAME side stream (only when a collective really starts:
-    not while a capture records markers)."""
+    """The reducer's bucket launch + a streaming load behind it on a second queue of this process — the reducer's own side stream
+    when it has one, else (RCCL: the collectives run on the process group's stream) a stream of the test that is ordered after the
+    launch stream exactly like a bucket's all-reduce (only when a collective really starts: not while a capture records markers)."""
     _plain_launch(b)
-    if getattr(red, "_capture", False) or red._stream is None:
+    if getattr(red, "_capture", False):
         return
-    with torch.cuda.stream(red._stream):
+    load_stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(load_stream):
         for _ in range(SIDE_PASSES):
             L.call("dm_cast", L.ptr(scratch_a), L.ptr(scratch_b), L.DM_F32, L.DM_F32, scratch_a.numel())
         side_launches[0] += SIDE_PASSES
