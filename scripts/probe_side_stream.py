@@ -47,15 +47,17 @@ def raw_run(kind, side, ev_a, ev_b, steps=40):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        hip.hipEventRecord(ev_a, main); hip.hipStreamWaitEvent(sd, ev_a, 0)
+        hip.hipEventRecord(ev_a, main)
+        if kind != "record_nowait":
+            hip.hipStreamWaitEvent(sd, ev_a, 0)
         if kind == "pair":
             hip.hipEventRecord(ev_b, sd); hip.hipStreamWaitEvent(main, ev_b, 0)
         step()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
 side0 = torch.cuda.Stream()
-for fname, flags in (("disable_timing", 0x2), ("disable_timing|release_to_device", 0x2 | 0x40000000), ("default(timing)", 0x0)):
-    for kind in ("record_only", "pair"):
+for fname, flags in (("disable_timing", 0x2), ("disable_timing|release_to_device", 0x2 | 0x40000000), ("disable_timing|no_system_fence", 0x2 | 0x20000000), ("default(timing)", 0x0)):
+    for kind in ("record_nowait", "record_only", "pair"):
         print(f"raw {fname:34s} {kind:12s} {raw_run(kind, side0, raw_event(flags), raw_event(flags)):7.3f} ms/step", flush=True)
 print(f"none {run('none', side0):7.3f}", flush=True)
 lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
