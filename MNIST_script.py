@@ -14,6 +14,9 @@ import torch
 
 from diffusionmodel_amd import FusedAdamW
 from diffusionmodel_amd.mnist import DDPM, ContextUnet
+# the other public names of the reference module (MNIST_script.py:31-216): `from MNIST_script import ResidualConvBlock` works
+from diffusionmodel_amd.mnist import ResidualConvBlock, UnetDown, UnetUp  # noqa: F401
+from diffusionmodel_amd import EmbedFC, ddpm_schedules  # noqa: F401
 
 
 def synthetic_digits(n, n_classes=10, seed=0):

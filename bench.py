@@ -216,6 +216,90 @@ def cpu_baseline(args):
                                      f"{t_ms * 1e3:.0f} ms; {n_it} timed iters each, full size (no scaling)"}}
 
 
+def _sysfs_gpu(local):
+    """Shader clock / power cap of the card as user space can read them (None where the box hides them)."""
+    import glob
+    out = {}
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+    try:
+        with open(cards[local]) as f:
+            lv = [ln.strip() for ln in f if ln.strip()]
+        out["sclk_levels_mhz"] = [int(ln.split(":")[1].strip().lower().replace("mhz", "").replace("*", "")) for ln in lv]
+        cur = [ln for ln in lv if ln.endswith("*")]
+        if cur:
+            out["sclk_now_mhz"] = int(cur[0].split(":")[1].strip().lower().replace("mhz", "").replace("*", ""))
+        base = os.path.dirname(cards[local])
+        for hw in glob.glob(os.path.join(base, "hwmon", "hwmon*")):
+            for key, fn in (("power_cap_w", "power1_cap"), ("power_now_w", "power1_average"), ("power_now_w", "power1_input")):
+                try:
+                    with open(os.path.join(hw, fn)) as f:
+                        out.setdefault(key, round(int(f.read()) / 1e6, 1))
+                except (OSError, ValueError):
+                    pass
+    except (OSError, IndexError, ValueError):
+        pass
+    return out or None
+
+
+def calibration(dev, iters=300):
+    """What THIS box does on three fixed probes, measured in this process right before the timed region, so that lines from
+    different boxes of the pool can be put on one scale (boxes differ by +-6 %, a round's work is 6 %):
+    (1) the 64x64 128->128 3x3 halo convolution alone (B = 64, bf16, 77.3 GFLOP), `iters` back-to-back launches on RANDOM operands —
+    the dominant kernel at its power-limited clock; (2) the same on ALL-ZERO operands — same cycles, no data toggling, the clock the
+    power limit leaves (the pair is the DVFS signature); (3) one 1-GiB fp32 device copy (dm_cast; 2 GiB of HBM
+    traffic); plus shader clock / power cap from sysfs when readable."""
+    from diffusionmodel_amd import ops
+    B, H, Ci, Co, k = 64, 64, 128, 128, 3
+    flops = 2.0 * B * H * H * Co * k * k * Ci
+    geom = dict(dtype=torch.bfloat16, B=B, Hi=H, Wi=H, C1=Ci, C2=0, Hq=H, Wq=H, sy=1, sx=1, T=9, KW=3, ty=1, tx=1, oy0=-1, ox0=-1, Ho=H, Wo=H, N=Co)
+    y = torch.empty(B, H, H, Co, device=dev, dtype=torch.bfloat16)
+    out = {"probe_conv": "conv3x3 halo kernel, 64x64, 128->128, B=64, bf16, %d back-to-back launches" % iters}
+    g = torch.Generator(device=dev).manual_seed(5)
+    for tag in ("random", "zeros"):
+        if tag == "random":
+            x = torch.randn(B, H, H, Ci, device=dev, generator=g).bfloat16()
+            w = (torch.randn(Co, k, k, Ci, device=dev, generator=g) / (Ci * k * k) ** 0.5).bfloat16()
+        else:
+            x, w = torch.zeros(B, H, H, Ci, device=dev, dtype=torch.bfloat16), torch.zeros(Co, k, k, Ci, device=dev, dtype=torch.bfloat16)
+        for _ in range(20):
+            ops._conv_call(x, None, w.data_ptr(), k * k * Ci, y, **geom)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops._conv_call(x, None, w.data_ptr(), k * k * Ci, y, **geom)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        out["conv_%s_us" % tag] = round(us, 2)
+        out["conv_%s_tflops" % tag] = round(flops / (us * 1e-6) / 1e12, 1)
+    del x, w, y
+    n = 1 << 28
+    a, b = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+    a.fill_(1.0)
+    for _ in range(2):
+        ops.call("dm_cast", ops.ptr(a), ops.ptr(b), ops.L.DM_F32, ops.L.DM_F32, n)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        ops.call("dm_cast", ops.ptr(a), ops.ptr(b), ops.L.DM_F32, ops.L.DM_F32, n)
+    e1.record()
+    torch.cuda.synchronize()
+    out["copy_1GiB_TBps"] = round(5 * 8.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e12, 3)
+    del a, b
+    torch.cuda.empty_cache()
+    out["sysfs"] = _sysfs_gpu(dev.index or 0)
+    return out
+
+
+def _calibration_ref():
+    """The calibration block of the box the committed rocprof profile was taken on (profiles/r04_calibration_ref.json)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_calibration_ref.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
 FAMILIES = (   # (family, substrings of kernel names) — first match wins
     ("conv", ("conv3x3_halo_kernel", "conv3x3_halo_pkernel", "conv3x3_packtap_kernel", "conv3x3_narrow_kernel", "conv_tap4_halo_kernel", "conv_pw_kernel",
               "conv_igemm", "splitk_epilogue")),
@@ -253,8 +337,14 @@ def self_launch(argv, n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    import threading
+    from diffusionmodel_amd.parallel import wait_ranks
+    buf = []
+    rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)     # drain rank 0's pipe while waiting
+    rd.start()
+    codes = wait_ranks(procs)                  # a rank that dies takes its siblings with it instead of leaving them in a collective
+    rd.join(timeout=10)
+    out = buf[0] if buf else ""
     line = [ln for ln in (out or "").splitlines() if ln.startswith("{")]
     if line:
         print(line[-1], flush=True)
@@ -296,6 +386,9 @@ def main():
     ap.add_argument("--n-feat", dest="n_feat", type=int, default=None)
     ap.add_argument("--bottleneck-k", dest="bottleneck_k", type=int, default=None)
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp32", "fp16"])
+    ap.add_argument("--repeats", type=int, default=5, help="the timed region of --steps steps is run this many times; `value` is the median")
+    ap.add_argument("--no-calibration", dest="calib", action="store_false")
+    ap.add_argument("--no-dp-probe", dest="dp_probe", action="store_false", help="skip the in-process one-rank RCCL probe of the N=1 run")
     ap.add_argument("--sample-steps", dest="sample_steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
     ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=0, help="batch of the CPU-baseline legs (default: --batch, i.e. the stated B=64)")
@@ -404,30 +497,49 @@ def main():
     for i in range(args.warmup):
         train_step(eager=(i == 0 and graphed is None))
     fence()
+    # ---- calibration probes of THIS box, in this process, before the timed region (rank 0 reports; every rank runs them so the
+    # ranks stay in step)
+    calib = calibration(dev) if (args.calib and args.config == "cfg2") else None
+    if calib is not None:
+        for i in range(2):                     # back to the step's own cache / clock state
+            train_step()
+        fence()
     # Per-launch HIP events on the launch stream, recorded during the LAST timed step only (~540 event records per step cost ~2 ms
     # of wall time, which would otherwise distort `value`).  plan: dm_plan_run_timed puts the event pairs around the halo-kernel
     # launches of the replay; eager / graph: the last step is launched eagerly with torch events around every MFMA launch.
     planned = graphed is not None and graphed.plan is not None
     no_events = bool(os.environ.get("DM_BENCH_NO_EVENTS"))
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        last = i == args.steps - 1 and not no_events
-        if last and planned:
-            plan = graphed.plan
-            if reducer is not None:
-                graphed._runner = lambda pl: reducer.replay(pl, run=lambda a, b: pl.run_timed("halo_kernel|halo_pkernel", a, b))
-            else:
-                graphed._runner = lambda pl: pl.run_timed("halo_kernel|halo_pkernel")
-            loss = train_step()
-            graphed._runner = reducer.replay if reducer is not None else None
-            continue
-        if last:
-            ops.PROFILE_KINDS = ("conv_igemm", "conv_halo", "conv_wgrad") if dtype != torch.float32 else ("igemm_f32", "wgrad_f32")
-            ops.PROFILE = []                   # (the instrumented step is launched eagerly: a replayed graph has no per-launch events)
-        loss = train_step(eager=last)
-    t_enq = time.perf_counter() - t0       # host time to enqueue the steps (the GPU runs behind it; with a full queue this is back-pressure)
-    fence()
-    elapsed = time.perf_counter() - t0
+    # The timed region — exactly --steps steps between fence() pairs — is run --repeats times; `value` is the MEDIAN region,
+    # min / max go beside it.  The per-launch events are recorded in the last step of the LAST region only.
+    regions, enq = [], []
+    for rep in range(max(1, args.repeats)):
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            last = i == args.steps - 1 and rep == max(1, args.repeats) - 1 and not no_events
+            if last and planned:
+                plan = graphed.plan
+                if reducer is not None:
+                    graphed._runner = lambda pl: reducer.replay(pl, run=lambda a, b: pl.run_timed("halo_kernel|halo_pkernel", a, b))
+                else:
+                    graphed._runner = lambda pl: pl.run_timed("halo_kernel|halo_pkernel")
+                loss = train_step()
+                graphed._runner = reducer.replay if reducer is not None else None
+                continue
+            if last:
+                ops.PROFILE_KINDS = ("conv_igemm", "conv_halo", "conv_wgrad") if dtype != torch.float32 else ("igemm_f32", "wgrad_f32")
+                ops.PROFILE = []                   # (the instrumented step is launched eagerly: a replayed graph has no per-launch events)
+            loss = train_step(eager=last)
+        enq.append(time.perf_counter() - t0)   # host time to enqueue the steps (the GPU runs behind it; with a full queue this is back-pressure)
+        fence()
+        el = time.perf_counter() - t0
+        if use_dp:                             # MAX over ranks, per region
+            tt = torch.tensor([el], device=dev)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            el = float(tt.item())
+        regions.append(el)
+    elapsed = sorted(regions)[len(regions) // 2]
+    t_enq = sorted(enq)[len(enq) // 2]
     prof, ops.PROFILE = ops.PROFILE or [], None
     prof_steps = 1                         # steps the event records cover
     timed = []                             # (kind, flops, seconds, shape)
@@ -451,10 +563,6 @@ def main():
     if rank == 0:
         print(f"[bench] exec={mode}: host enqueue {t_enq / args.steps * 1e3:.2f} ms/step under load, {t_host_one * 1e3:.2f} ms for one step on an idle "
               f"queue; wall {elapsed / args.steps * 1e3:.2f} ms/step", file=sys.stderr)
-    if use_dp:
-        tt = torch.tensor([elapsed], device=dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt.item())
     final_loss = float(loss.item())
     devices = [f"cuda:{local}"]
     if use_dp:
@@ -554,6 +662,13 @@ def main():
         for k_, (ms_, n_) in cand:
             hbm_rows.append({"kernel": k_, "launches": n_, "ms_per_step": round(ms_, 4), "algorithmic_bytes_per_step": int(alg[k_]),
                              "achieved_GBps": round(alg[k_] / (ms_ * 1e-3) / 1e9, 1), "frac_of_8TBps": round(alg[k_] / (ms_ * 1e-3) / 8e12, 4)})
+    # the same fraction put on the scale of the box the committed rocprof profile was taken on: x (this box's probe time / that box's)
+    ref_cal, frac_cal, frac_cal_note = _calibration_ref(), None, None
+    if calib is not None and ref_cal and ref_cal.get("conv_random_us"):
+        ratio = calib["conv_random_us"] / ref_cal["conv_random_us"]
+        frac_cal = round(ach / peak * ratio, 4)
+        frac_cal_note = ("frac x (this box's conv_random_us %.2f / the profile box's %.2f = %.3f): the dominant kernel's fraction as the box of "
+                         "profiles/%s would have measured it" % (calib["conv_random_us"], ref_cal["conv_random_us"], ratio, ref_cal.get("profile", "r04_train_kernel_stats.csv")))
     roofline = {"bound": "mfma", "kernel": ("conv3x3_halo_kernel<%s> (dm_conv forward + input-gradient launches of the 3x3 layers)" if dom == "conv_halo"
                                             else "conv_igemm2_kernel<%s> (dm_conv forward + input-gradient launches)") % args.dtype,
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
@@ -561,6 +676,7 @@ def main():
                 "traffic_kernel": "conv3x3_halo_kernel",
                 "algorithmic_bytes_per_launch": None if alg_bytes is None else int(alg_bytes),
                 "algorithmic_bytes_note": "average over this kernel's launches of: input read once + weights + output written once",
+                "frac_calibrated": frac_cal, "frac_calibrated_note": frac_cal_note,
                 "launches": fl[dom][2], "avg_launch_us": round(fl[dom][1] / max(fl[dom][2], 1) * 1e6, 2),
                 "algorithmic_tflop_per_step": round(fl[dom][0] / prof_steps / 1e12, 4),
                 "events": ("HIP event pairs on the launch stream around every halo-kernel launch of the LAST TIMED step (dm_plan_run_timed)") if planned else
@@ -624,6 +740,63 @@ def main():
             sample = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         ddpm.train()
 
+    # ---- data-parallel facts of this run: what the N > 1 curve is read against
+    dp = None
+    if use_dp and planned:
+        reducer.time_tail = True
+        tails = []
+        for _ in range(5):
+            train_step()
+            tails.append(reducer.tail_wait_ms())
+        reducer.time_tail = False
+        dp = {"ranks": ranks_seen, "buckets": len(reducer.buckets), "allreduce_bytes_per_step_per_rank": reducer.bytes_per_step(),
+              "bucket_bytes": [4 * (b["hi"] - b["lo"]) for b in reducer.buckets],
+              "tail_wait_ms": round(sorted(tails)[len(tails) // 2], 3),
+              "tail_wait_note": "launch-stream time between the last backward kernel and all bucket all-reduces done (event pair in "
+                                "OverlappedGradReducer.replay), median of 5 steps after the timed regions: the part of the reduction the backward pass did not hide",
+              "collectives_on": "side stream" if reducer._stream is not None else "launch stream -> RCCL's own stream", "force_dp": bool(args.force_dp)}
+    elif world == 1 and planned and args.dp_probe and args.config == "cfg2":
+        # plain N = 1 (the line's value) next to the SAME process driving the one-rank RCCL path (--force-dp): the floor under
+        # every point of the N > 1 curve.  Built after the timed regions; a failure here must not lose the line.
+        try:
+            parallel.init_from_env("nccl", force=True)
+            red2 = parallel.OverlappedGradReducer(opt, n_buckets=args.buckets)
+
+            def body2(st):
+                opt.zero_grad()
+                red2.begin(capture=torch.cuda.is_current_stream_capturing())
+                loss_ = ddpm(st.x, st.c, st.am)
+                ddpm.scaler.scale(loss_).backward()
+                red2.finish()
+                ddpm.scaler.step(opt)
+                return loss_
+            g2 = D.GraphedTrainStep(ddpm, opt, x, c, am, mode="plan", body=body2, runner=red2.replay)
+
+            def region(fn):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / args.steps * 1e3
+            for _ in range(3):
+                g2()
+            a_, b_ = [], []
+            for _ in range(3):                 # alternate, same box, same minute
+                a_.append(region(graphed))
+                b_.append(region(g2))
+            red2.time_tail = True
+            g2()
+            dp = {"ranks": 1, "n1_plain_ms_per_step": [round(v, 3) for v in a_], "n1_force_dp_ms_per_step": [round(v, 3) for v in b_],
+                  "force_dp_overhead_ms": round(sorted(b_)[1] - sorted(a_)[1], 3), "buckets": len(red2.buckets),
+                  "allreduce_bytes_per_step_per_rank": red2.bytes_per_step(), "tail_wait_ms": round(red2.tail_wait_ms(), 3),
+                  "note": "in-process probe after the timed regions: the planned step re-captured with OverlappedGradReducer over a one-rank RCCL "
+                          "group, alternated three times with the plain plan (%d steps per region)" % args.steps}
+            red2.time_tail = False
+            torch.distributed.destroy_process_group()
+        except Exception as exc:              # noqa: BLE001 — reported in the JSON
+            dp = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu:
         cpu = cpu_baseline(args)
@@ -632,14 +805,21 @@ def main():
         value = world * args.steps / elapsed
         out = {"metric": f"denoiser-steps/sec (train fwd+bwd+clip+AdamW, {args.size}x{args.size}, B={args.batch}/GPU)", "value": round(value, 4),
                "unit": "steps/s", "n_gpus": world, "ranks": ranks_seen, "devices": devices, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+               "repeats": {"n": len(regions), "of_steps": args.steps, "value_is": "median region",
+                           "ms_per_step_all": [round(r / args.steps * 1e3, 3) for r in regions],
+                           "ms_per_step_min": round(min(regions) / args.steps * 1e3, 3), "ms_per_step_max": round(max(regions) / args.steps * 1e3, 3)},
+               "calibration": calib, "calibration_ref": ref_cal,
+               "ms_per_step_calibrated": (None if not (calib and ref_cal and ref_cal.get("conv_random_us")) else
+                                          round(elapsed / args.steps * 1e3 * ref_cal["conv_random_us"] / calib["conv_random_us"], 3)),
+               "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "new_scripy.py ContextUnet %dx%d n_feat=%d T=1000 %s, train step batch=%d per GPU (BASELINE configs[%d])"
                                       % (args.size, args.size, args.n_feat, args.dtype, args.batch, 4 if args.config == "cfg5" else (1 if world == 1 else 2)),
                           "preset": args.config,
                           "global_batch": args.batch * world, "bottleneck_k": args.bottleneck_k, "n_classes": 4,
                           "parallelism": "dp%d" % world, "backend": args.backend if use_dp else None, "exec": mode, "host_ms_one_step_idle_queue": round(t_host_one * 1e3, 3), "samples_per_s": round(value * args.batch, 2)},
-               "loss": final_loss, "roofline": roofline, "cpu_baseline": cpu, "sample": sample}
+               "loss": final_loss, "roofline": roofline, "cpu_baseline": cpu, "sample": sample, "dp": dp}
         print(json.dumps(out), file=json_out, flush=True)
     if use_dp:
         torch.distributed.destroy_process_group()

@@ -735,6 +735,7 @@ static TnJob tn_job(int& next, int M, int K, int N) {
     return j;
 }
 
+constexpr size_t DM_CA_CHAIN_SMALL_LDS = (64 - 22) * 1024;
 static int ca_geometry(const DmCaChain* d, const char* who, int nmat, int& Hp, int& Wp, int& LD, size_t& lds) {
     if (!(d && d->B > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->R > 0)) { dm_set_error("%s: bad geometry", who); return DM_EINVAL; }
     if (d->C % 4 || d->R % 4 || d->R > 128) { dm_set_error("%s: C %% 4 == 0, R %% 4 == 0, R <= 128 (got C=%d R=%d)", who, d->C, d->R); return DM_EINVAL; }
@@ -743,6 +744,13 @@ static int ca_geometry(const DmCaChain* d, const char* who, int nmat, int& Hp, i
     LD = d->R + 4;
     lds = ((size_t)nmat / 2 * (Hp + Wp) * LD + 8 * d->R) * sizeof(float);
     if (lds > 120 * 1024) { dm_set_error("%s: strips of %d + %d positions x %d channels need %zu B of LDS", who, d->H, d->W, d->R, lds); return DM_EINVAL; }
+    // The <= 64-KiB rule of a GPU shared between processes (conv variant 2, selected by the device guard: DESIGN.md section 6) binds the
+    // chain kernels too: dynamic strips + <= 22 KiB of static scratch must stay inside 64 KiB.  The host then falls back to
+    // the one-launch-per-op path (ops.ca_chain_ok) — this refusal is the backstop for callers of the C ABI.
+    if (dm_get_conv_variant() == 2 && lds > DM_CA_CHAIN_SMALL_LDS) {
+        dm_set_error("%s: %zu B of strip LDS (+ 22 KiB static) exceed the 64-KiB workgroup limit of a shared device (conv variant 2)", who, lds);
+        return DM_EUNSUPPORTED;
+    }
     return DM_OK;
 }
 

@@ -1042,9 +1042,24 @@ class CaGate(torch.autograd.Function):
         return dx, dlh, dlw, dab[0:1], dab[1:2]
 
 
-def ca_chain_ok(C_, R):
-    """Shapes the fused CoordAttn strip chain (chain.hip) takes: C % 4 == 0, R % 4 == 0, R <= 128."""
-    return FUSED_CHAINS and C_ % 4 == 0 and R % 4 == 0 and 0 < R <= 128
+def ca_chain_lds(H, W, R):
+    """Dynamic LDS bytes of ca_mix / ca_bwd_mix (chain.hip:ca_geometry): three strip matrices of (Hp + Wp) x (R + 4) floats + 8 R."""
+    hp, wp = -(-H // 16) * 16, -(-W // 16) * 16
+    return (3 * (hp + wp) * (R + 4) + 8 * R) * 4
+
+
+def ca_chain_ok(C_, R, H=None, W=None):
+    """Shapes the fused CoordAttn strip chain (chain.hip) takes: C % 4 == 0, R % 4 == 0, R <= 128, strips inside 120 KiB of LDS — and
+    inside 42 KiB (+ 22 KiB static = 64 KiB per workgroup) when the library runs its small-LDS kernels because the GPU is shared
+    between processes (_lib.device_guard / parallel.guard_shared_device -> conv variant 2)."""
+    if not (FUSED_CHAINS and C_ % 4 == 0 and R % 4 == 0 and 0 < R <= 128):
+        return False
+    if H is None:
+        return True
+    need = ca_chain_lds(H, W, R)
+    if need > 120 * 1024:
+        return False
+    return not (L.load().dm_get_conv_variant() == 2 and need > (64 - 22) * 1024)
 
 
 class CaChain(torch.autograd.Function):

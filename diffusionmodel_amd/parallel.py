@@ -355,6 +355,10 @@ class OverlappedGradReducer:
             if 0 <= m < len(self.buckets):
                 self._launch(m)
             elif m == self.MARK_BACKWARD_DONE:
+                timing = getattr(self, "time_tail", False)
+                if timing:                            # launch-stream time between the last backward kernel and the reduced buckets
+                    self._tail_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    self._tail_ev[0].record()
                 for b in range(len(self.buckets)):
                     if not self._launched[b]:
                         self._launch(b)
@@ -362,6 +366,8 @@ class OverlappedGradReducer:
                     w.wait()
                 if self._stream is not None:
                     torch.cuda.current_stream().wait_stream(self._stream)
+                if timing:
+                    self._tail_ev[1].record()
                 self._works = []
             elif m == self.MARK_SMALL_PACKED:
                 if self._drain:
@@ -370,6 +376,45 @@ class OverlappedGradReducer:
                     dist.all_reduce(self._packed, op=dist.ReduceOp.SUM, group=self.group)
             elif m != -1:
                 raise DmError(f"OverlappedGradReducer.replay: unknown plan marker {m}")
+
+
+    def tail_wait_ms(self):
+        """With `time_tail = True`: launch-stream milliseconds of the last replay between the end of the backward pass and the
+        moment every bucket's all-reduce had finished (what the overlap did NOT hide).  Synchronises."""
+        ev = getattr(self, "_tail_ev", None)
+        if ev is None:
+            return None
+        ev[1].synchronize()
+        return float(ev[0].elapsed_time(ev[1]))
+
+    def bytes_per_step(self):
+        """Bytes this rank hands to all-reduce per optimiser step: the flat fp32 gradient in buckets + the packed small gradients."""
+        return 4 * (int(self.flat.numel()) + int(self._small_total))
+
+
+def wait_ranks(procs, poll=0.2):
+    """Wait for the child ranks; when one exits non-zero the others are terminated (they would otherwise sit in a collective
+    until the RCCL timeout).  Returns the list of exit codes."""
+    import time
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = p.wait(timeout=20)
+                    except Exception:                 # noqa: BLE001
+                        p.kill()
+                        codes[i] = p.wait()
+            break
+        time.sleep(poll)
+    return codes
 
 
 def launch_ranks(script, argv, n, extra_env=None):
@@ -389,7 +434,7 @@ def launch_ranks(script, argv, n, extra_env=None):
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env,
                                       stdout=None if r == 0 else sys.stderr))
-    codes = [p.wait() for p in procs]
+    codes = wait_ranks(procs)
     bad = [c for c in codes if c]
     return bad[0] if bad else 0
 

@@ -55,6 +55,10 @@ class TrainEngine:
         self._planned, self._plan_shape = None, None
         self._in_group = 0            # local micro-batches accumulated since the last optimiser step
         self.opt_steps = 0
+        # a replayed plan zeroes the flat gradient buffer at its START only (the capture cannot end with the fill: AdamW reads the
+        # buffer last), so after a replay flat_g still holds that step's reduced gradient; the next EAGER group (short tail batch,
+        # injected draws, an idle slot) must not accumulate on top of it
+        self._stale_grad = False
         opt.zero_grad()
 
     # ---- the eager step pieces ------------------------------------------------------------------
@@ -65,8 +69,17 @@ class TrainEngine:
             self.reducer.begin(capture=torch.cuda.is_current_stream_capturing())
         sc.scale(loss).backward()                                                   # :792
 
+    def _fresh_grad(self):
+        if self._stale_grad:
+            if self._in_group:
+                raise DmError("TrainEngine: a plan replay inside an open accumulation group")
+            self.opt.zero_grad()
+            self._stale_grad = False
+
     def _close_group(self, idle=False):
         sc = self.ddpm.scaler
+        if idle:
+            self._fresh_grad()
         if self.reducer is not None:
             if idle:                                   # no backward pass ran under the reducer for this group: nothing was overlapped
                 self.reducer.begin()
@@ -98,9 +111,13 @@ class TrainEngine:
                 and self.ddpm.training:
             if self._planned is None:
                 self._build_plan(x, c, attn_mask)
+            steps0 = self.opt_steps
             loss = self._planned(x, c, attn_mask)
-            self.opt_steps += 1
+            # (a plan that fell back to eager issue — shared GPU — ran _body -> _close_group, which counted and zeroed already)
+            self._stale_grad = not self._planned._fallback_eager
+            self.opt_steps = steps0 + 1
             return loss.detach().clone()
+        self._fresh_grad()
         loss = self.ddpm(x, c, attn_mask, **draws) / self.loss_div                  # :784-786
         self._backward(loss, closing)
         self._in_group += 1

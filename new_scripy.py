@@ -22,7 +22,11 @@ import numpy as np
 import torch
 
 from diffusionmodel_amd import Cfg, ContextUnet, DDPM, FusedAdamW
+# every public name of the reference module resolves here too (new_scripy.py:70-268, 358, 479, 1111): `from new_scripy import ResConvBlock`
+from diffusionmodel_amd import CoordAttn, EmbedFC, LocalEnhancer, ResConvBlock, SEBlock, UnetDown, UnetUp, ddpm_schedules  # noqa: F401
 from diffusionmodel_amd import parallel
+from diffusionmodel_amd.data import CrackDataset  # noqa: F401
+from diffusionmodel_amd.metrics import ImageMetrics  # noqa: F401
 from diffusionmodel_amd.train import StridedBatchSampler, TrainEngine, reduce_mean_scalar
 
 
@@ -113,7 +117,15 @@ def build_model(n_classes, device, drop_prob=None):
 
 
 def split_indices(labels, val_split, seed=42):
-    """Per-class (stratified) train / validation split of sample indices, like the reference's split (new_scripy.py:622-657)."""
+    """Stratified train / validation split of sample indices (new_scripy.py:628-633).  With scikit-learn importable — the
+    reference's own dependency — it IS the reference's split: StratifiedShuffleSplit(n_splits=1, test_size=val_split,
+    random_state=42); otherwise (or when a class has a single member, which sklearn refuses) a per-class seeded permutation."""
+    try:
+        from sklearn.model_selection import StratifiedShuffleSplit
+        tr, va = next(StratifiedShuffleSplit(n_splits=1, test_size=val_split, random_state=seed).split(np.zeros(len(labels)), labels))
+        return [int(i) for i in tr], [int(i) for i in va]
+    except (ImportError, ValueError):
+        pass
     g = torch.Generator().manual_seed(seed)
     tr, va = [], []
     for cls in sorted(set(labels)):
@@ -123,6 +135,42 @@ def split_indices(labels, val_split, seed=42):
         va += perm[:n_val]
         tr += perm[n_val:]
     return tr, va
+
+
+def create_loaders(dataset, batch_size, val_split=Cfg.VAL_SPLIT, num_workers=Cfg.NUM_WORKERS, pin_mem=Cfg.PIN_MEM, *, rank=0, world=1, seed=0):
+    """new_scripy.py:622-657: stratified split of `dataset` (labels = dataset.samples[i][2]) and the two loaders — train shuffled,
+    validation in order, no drop_last.  rank / world (keyword-only additions): the loaders of ONE rank of a data-parallel job —
+    micro-batch m of the epoch's single seeded permutation goes to rank m % world (train.StridedBatchSampler; call
+    `train_loader.batch_sampler.set_epoch(ep)` per epoch) — with world == 1 they are the reference's loaders."""
+    from torch.utils.data import DataLoader, Subset
+    labels = [dataset.samples[i][2] for i in range(len(dataset))]
+    train_idx, val_idx = split_indices(labels, val_split)
+    train_set, val_set = Subset(dataset, train_idx), Subset(dataset, val_idx)
+    print(f"Dataset split - Train: {len(train_set)} samples, Val: {len(val_set)} samples")
+    if world > 1:
+        tb = StridedBatchSampler(len(train_set), batch_size, rank, world, shuffle=True, seed=seed)
+        vb = StridedBatchSampler(len(val_set), batch_size, rank, world, shuffle=False)
+        return (DataLoader(train_set, batch_sampler=tb, num_workers=num_workers, pin_memory=pin_mem),
+                DataLoader(val_set, batch_sampler=vb, num_workers=num_workers, pin_memory=pin_mem))
+    return (DataLoader(train_set, batch_size=batch_size, shuffle=True, num_workers=num_workers, pin_memory=pin_mem),
+            DataLoader(val_set, batch_size=batch_size, shuffle=False, num_workers=num_workers, pin_memory=pin_mem))
+
+
+def gen_and_save(model, n_samples, img_size, device, guide_scales, save_dir, classes=None, denorm=True, samples_per_class=None):
+    """new_scripy.py:563-585: one `model.sample` call per guide scale (samples_per_class x len(classes) images when
+    samples_per_class is given, else n_samples), the grid written to save_dir/samples_g{w}.png with samples_per_class images per
+    row; returns {w: {"samples", "grid_path"}}."""
+    results = {}
+    n_classes = len(classes) if classes else 1
+    with torch.no_grad():
+        for guide_scale in guide_scales:
+            print(f"\nGenerating samples with guidance scale {guide_scale}")
+            n_sample = samples_per_class * n_classes if samples_per_class else n_samples
+            x_gen = model.sample(n_sample, (Cfg.IN_CH, *img_size), device, guide_w=guide_scale)
+            grid_path = os.path.join(save_dir, f"samples_g{guide_scale}.png")
+            save_samples(x_gen, grid_path, nrow=samples_per_class, denorm=denorm)
+            results[guide_scale] = {"samples": x_gen, "grid_path": grid_path}
+    return results
 
 
 def _jsonable(v):
@@ -183,7 +231,7 @@ def train_model(n_classes=4, n_train=64, n_val=16, max_epochs=None, device="cuda
     S = Cfg.IMG_SIZE
     to_mask = lambda am: am.to(device)
     if data_root:       # the reference's layout (images/<class>/..., annotations/*.xml); masks are rasterised on the device
-        from diffusionmodel_amd.data import CrackDataset, attn_masks
+        from diffusionmodel_amd.data import attn_masks
         full = CrackDataset(data_root, S, return_boxes=True)
         n_classes = len(full.classes)
         tr_idx, va_idx = split_indices([s[2] for s in full.samples], Cfg.VAL_SPLIT)
@@ -219,7 +267,7 @@ def train_model(n_classes=4, n_train=64, n_val=16, max_epochs=None, device="cuda
             f"({engine.local_accum} per rank)")
     if train_bs.n_batches < world:
         raise SystemExit(f"{train_bs.n_batches} micro-batches per epoch cannot feed {world} ranks")
-    early_stop = EarlyStop(verbose=not quiet and chief)
+    early_stop = EarlyStop(patience=Cfg.PATIENCE, min_delta=Cfg.MIN_DELTA, verbose=not quiet and chief)
     n_epoch = Cfg.N_EPOCH if max_epochs is None else max_epochs
 
     def save_ckpt(epoch, loss, is_best=False):                                             # :730-744
@@ -275,7 +323,13 @@ def train_model(n_classes=4, n_train=64, n_val=16, max_epochs=None, device="cuda
         metrics_log["val_loss"].append(va)
         history.append({"epoch": ep, "train_loss": tr, "val_loss": va, "lr": optim.param_groups[0]["lr"], "time": time.time() - t0})
         say(f"epoch {ep}: train {tr:.4f} val {va:.4f} lr {optim.param_groups[0]['lr']:.2e} ({time.time() - t0:.1f}s)")
-        is_best = early_stop(va, ddpm if chief else None, ep)                              # :838 (the same decision on every rank)
+        is_best = early_stop(va, ddpm if chief else None, ep)                              # :838
+        if world > 1:
+            # every rank saw the same all-reduced `va`, so the decisions agree; rank 0's is nevertheless the one that counts — a
+            # rank that stopped alone would leave its peers waiting in the next step's collectives
+            flags = [bool(is_best), bool(early_stop.early_stop)]
+            torch.distributed.broadcast_object_list(flags, src=0)
+            is_best, early_stop.early_stop = flags
         if early_stop.early_stop:                                                          # :839-845
             if chief and early_stop.best_state:
                 torch.save(early_stop.best_state, os.path.join(Cfg.SAVE_DIR, "best_model_early.pt"))
@@ -320,6 +374,15 @@ def train_model(n_classes=4, n_train=64, n_val=16, max_epochs=None, device="cuda
     elif early_stop.best_state and early_stop.best_state["model_state_dict"] is not None:  # :934-936
         ddpm.load_state_dict(early_stop.best_state["model_state_dict"])
         optim.refresh_shadow()
+    if world > 1:
+        # the ranks must leave with the same model: one tiny collective (sum and sum of squares of the flat parameter buffer in
+        # float64) — a mismatch is a bug in the reduction / broadcast path and must not pass silently
+        chk = torch.stack([optim.flat_p.double().sum(), (optim.flat_p.double() ** 2).sum()]).cpu()
+        allc = [None] * world
+        torch.distributed.all_gather_object(allc, [float(v) for v in chk])
+        if any(a != allc[0] for a in allc):
+            raise RuntimeError(f"[data parallel] parameters differ between ranks at exit: {allc}")
+        say(f"[data parallel] parameters identical on {world} ranks (checksum {allc[0][0]:.9e} / {allc[0][1]:.9e})")
     ddpm.train_engine = engine
     return ddpm, history
 
@@ -334,7 +397,7 @@ def _classes_of_checkpoint(sd):
 
 
 def gen_samples(ckpt_path, n_samples_per_class=Cfg.SAMPLES_PER_CLASS, guide_scales=None, denorm=True, eval_quality=True,
-                n_classes=None, class_names=None, real_images=None, device="cuda:0", use_graph=True, data_root=None):
+                n_classes=None, class_names=None, real_images=None, device="cuda:0", use_graph=True, data_root=None, seed=None, save_raw=False):
     """new_scripy.py:945-1108.  Class count / names come from `data_root` (the reference's dataset layout) when given, otherwise
     from the checkpoint itself; per-image PNGs are named <class>_s<k>_g<w>.png; SSIM / PSNR against `real_images` (or the first
     images of `data_root`) unless eval_quality is off."""
@@ -373,7 +436,14 @@ def gen_samples(ckpt_path, n_samples_per_class=Cfg.SAMPLES_PER_CLASS, guide_scal
     results, quality = {}, {}
     for gi, w in enumerate(guide_scales):
         n_sample = n_samples_per_class * n_classes
-        x_gen = _sample_all_ranks(ddpm, n_sample, (Cfg.IN_CH, S, S), device, w, stamp[0] + gi, world, use_graph=use_graph)   # :1036-1041
+        # `seed` (addition; the reference never seeds): the images are then a function of (checkpoint, seed, guide scale) alone —
+        # whatever the number of ranks (the shards draw their slice of one noise stream)
+        if seed is None:
+            x_gen = _sample_all_ranks(ddpm, n_sample, (Cfg.IN_CH, S, S), device, w, stamp[0] + gi, world, use_graph=use_graph)   # :1036-1041
+        else:
+            x_gen = parallel.sample_sharded(ddpm, n_sample, (Cfg.IN_CH, S, S), device, guide_w=w, seed=int(seed) + gi, use_graph=use_graph)
+        if chief and save_raw:
+            torch.save(x_gen.detach().float().cpu(), os.path.join(samples_dir, f"samples_g{w}.pt"))
         grid_path = os.path.join(samples_dir, f"samples_g{w}.png")
         results[w] = {"samples": x_gen, "grid_path": grid_path}
         if not chief:
@@ -410,6 +480,15 @@ def main(argv=None):
     ap.add_argument("--batch_size", type=int, default=None)
     ap.add_argument("--dtype", choices=["float32", "bfloat16", "float16"], default=None)
     ap.add_argument("--bottleneck_k", type=int, default=None)
+    ap.add_argument("--accum_steps", type=int, default=None)
+    ap.add_argument("--patience", type=int, default=None)
+    ap.add_argument("--min_delta", type=float, default=None)
+    ap.add_argument("--save_dir", default=None)
+    ap.add_argument("--sample_dir", default=None)
+    ap.add_argument("--n_train", type=int, default=64, help="size of the synthetic training set (no --data_root)")
+    ap.add_argument("--n_val", type=int, default=16, help="size of the synthetic validation set (no --data_root)")
+    ap.add_argument("--seed", type=int, default=None, help="--mode generate: seed of the sampling noise (default: the wall clock, like the unseeded reference)")
+    ap.add_argument("--save_raw", action="store_true", help="--mode generate: also write the float32 images of every guide scale as samples_g{w}.pt")
     ap.add_argument("--gpus", type=int, default=None, help="start this many ranks (one process per GPU, RCCL data parallel); the same as "
                                                            "running the script under torch.distributed.run --nproc-per-node N")
     ap.add_argument("--no_plan", action="store_true", help="issue every training step eagerly (default: a fixed-shape step is captured once "
@@ -431,16 +510,24 @@ def main(argv=None):
         print(f"wrote {convert_supervisely(*a.convert_supervisely)} images under {a.convert_supervisely[1]}")
         return
     for name, val in (("IMG_SIZE", a.img_size), ("N_FEAT", a.n_feat), ("N_T", a.n_T), ("BATCH_SIZE", a.batch_size),
-                      ("DTYPE", a.dtype), ("BOTTLENECK_K", a.bottleneck_k)):
+                      ("DTYPE", a.dtype), ("BOTTLENECK_K", a.bottleneck_k), ("ACCUM_STEPS", a.accum_steps), ("PATIENCE", a.patience),
+                      ("MIN_DELTA", a.min_delta), ("SAVE_DIR", a.save_dir), ("SAMPLE_DIR", a.sample_dir)):
         if val is not None:
             setattr(Cfg, name, val)
     if a.mode == "train":
         kw = {"use_plan": False} if a.no_plan else {}
+        if (a.n_train, a.n_val) != (64, 16):
+            kw.update(n_train=a.n_train, n_val=a.n_val)
+        if a.guide_scales:
+            Cfg.GUIDE_SCALES = list(a.guide_scales)
         train_model(max_epochs=a.epochs, data_root=a.data_root, **kw)
     else:
         if not a.ckpt:
             ap.error("--mode generate needs --ckpt/--checkpoint")
-        gen_samples(a.ckpt, n_samples_per_class=a.samples, guide_scales=a.guide_scales, eval_quality=not a.no_eval, data_root=a.data_root)
+        kw = {}
+        if a.seed is not None or a.save_raw:
+            kw = {"seed": a.seed, "save_raw": a.save_raw}
+        gen_samples(a.ckpt, n_samples_per_class=a.samples, guide_scales=a.guide_scales, eval_quality=not a.no_eval, data_root=a.data_root, **kw)
 
 
 if __name__ == "__main__":

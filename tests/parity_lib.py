@@ -267,6 +267,50 @@ def f128_b2_case(dtype, modes=("eval", "train")):
     return out
 
 
+def f128_b2_band_case(dtype=torch.bfloat16, modes=("eval", "train")):
+    """Per-child gradient-norm errors of the HIP path and of the REFERENCE's autocast(bfloat16) run as DISTRIBUTIONS: the f128_b2
+    case on its own input (j = 0, f128_b2.npz) and on K = 5 inputs 1e-3 of noise away from it (f128_b2_band.npz,
+    make_golden.py:gen_f128_b2_band — reference float64 and autocast norms per input).  One input is one rounding-noise realisation:
+    the reference's own worst-child error over these six inputs spans 0.023 .. 0.138 in eval mode."""
+    import diffusionmodel_amd as D
+    tag, B, S, F = "f128_b2", 2, 64, 128
+    g0, gb = npz(tag), npz(tag + "_band")
+    K = int(gb["K"])
+    ls = _loss_scale(dtype)
+    spec = O.context_unet_spec(3, F, 4, 4)
+    sd = synth.synth_state(spec)
+    x0 = si(tag + ".x", (B, 3, S, S))
+    c, t, mk = torch.tensor(g0["c"]), torch.tensor(g0["t"]), torch.tensor(g0["ctx_mask"])
+    probe = si(tag + ".probe", (B, 3, S, S))
+    out = {}
+    for mode in modes:
+        hip_err, ref_err = [], []
+        net = D.ContextUnet(3, F, 4, bottleneck_k=4, dtype=dtype)
+        for j in range(K + 1):
+            x = x0 if j == 0 else x0 + float(gb["pert_scale"]) * synth.synth_noise(f"{tag}.pert{j}", (B, 3, S, S))
+            key = (lambda q, cn: f"{mode}.{q}.{cn}") if j == 0 else (lambda q, cn, j=j: f"{j}.{mode}.{q}.{cn}")
+            g = g0 if j == 0 else gb
+            net.load_state_dict(sd, strict=True)
+            net = net.to(DEV)
+            net.train(mode == "train")
+            net.zero_grad()
+            eps = net(x.to(DEV), c.to(DEV), t.to(DEV), mk.to(DEV))
+            ((eps * probe.to(DEV)).mean() * ls).backward()
+            norms = {cn: float(np.linalg.norm(v)) / ls for cn, v in child_grad_vectors(net).items()}
+            kids = [cn for cn in norms if cn != "local_enhance" and key("gn64", cn) in g.files and float(g[key("gn64", cn)]) > 0]
+            hip_err.append({cn: norms[cn] / float(g[key("gn64", cn)]) - 1.0 for cn in kids})
+            ref_err.append({cn: float(g[key("gn_bf16", cn)]) / float(g[key("gn64", cn)]) - 1.0 for cn in kids})
+        kids = list(hip_err[0])
+        rms = lambda rows: float(np.sqrt(np.mean([v * v for r in rows for v in r.values()])))
+        out[mode] = {"inputs": K + 1, "hip_worst_child_per_input": [max(abs(v) for v in r.values()) for r in hip_err],
+                     "ref_autocast_worst_child_per_input": [max(abs(v) for v in r.values()) for r in ref_err],
+                     "hip_pooled_rms": rms(hip_err), "ref_autocast_pooled_rms": rms(ref_err),
+                     "hip_rms_per_child": {cn: float(np.sqrt(np.mean([r[cn] ** 2 for r in hip_err]))) for cn in kids},
+                     "ref_autocast_rms_per_child": {cn: float(np.sqrt(np.mean([r[cn] ** 2 for r in ref_err]))) for cn in kids}}
+        del net
+    return out
+
+
 def cfg2_full_size_case(B=64, S=64, F=128):
     """BASELINE configs[1] at its stated size (64x64, n_feat = 128, k = 4, B = 64, bf16), train mode, forward only: eps of the HIP
     path and the DDPM.forward loss (draws injected) against the float32 oracle on the same weights; yardstick = the oracle under
@@ -300,6 +344,46 @@ def cfg2_full_size_case(B=64, S=64, F=128):
     return {"eps_mse_vs_oracle32": float(((eps - e32) ** 2).mean()), "oracle_autocast_bf16_mse": float(((e16 - e32) ** 2).mean()),
             "eps_maxabs_vs_oracle32": float(np.abs(eps - e32).max()), "oracle_autocast_bf16_maxabs": float(np.abs(e16 - e32).max()),
             "signal_power": float((e32 ** 2).mean()), "loss": loss, "loss_oracle32": l32, "B": B}
+
+
+def sample_f128_case(n=16, steps=3, w=2.0, S=64, F=128, n_T=1000, seed=1234):
+    """BASELINE configs[3] on the benchmarked kernel set (bf16, n_feat = 128, hipGraph replay, encoder de-dup, broadcast skip
+    tensors, BatchNorm folded into the conv epilogues): `steps` CFG sampling steps (new_scripy.py:441-477) against the float32
+    oracle on the same weights, start noise and per-step noise; yardstick = the oracle under torch.autocast("cpu", bfloat16).
+    The graph draws its noise in-kernel (Philox: key = seed, counter high word = the step index i, low word = the element quad);
+    the same numbers are regenerated with dm_randn_slice and injected into the oracle — and into an eager HIP run with `zs=`,
+    which must agree with the replayed graph."""
+    import diffusionmodel_amd as D
+    from diffusionmodel_amd import ops
+    torch.manual_seed(977)
+    net = D.ContextUnet(3, F, 4, bottleneck_k=4, dtype=torch.bfloat16)
+    with torch.no_grad():
+        for n_, b in net.named_buffers():
+            if n_.endswith("running_mean"):
+                b.normal_(0, 0.1)
+            elif n_.endswith("running_var"):
+                b.uniform_(0.6, 1.4)
+    sd = {k: v.detach().clone().cpu() for k, v in net.state_dict().items()}
+    ddpm = D.DDPM(net, (1e-4, 0.02), n_T, DEV, drop_prob=0.1)
+    ddpm.eval()
+    shape = (n, 3, S, S)
+    x_T = ops.randn(shape, DEV, seed, 0)
+    zs = [ops.randn(shape, DEV, seed, n_T - j) for j in range(steps)]
+    xg = ddpm.sample(n, (3, S, S), DEV, guide_w=w, use_graph=True, seed=seed, steps=steps).cpu().double().numpy()
+    xe = ddpm.sample(n, (3, S, S), DEV, guide_w=w, x_T=x_T, zs=zs, steps=steps).cpu().double().numpy()
+    xT, zc = x_T.cpu(), [z.cpu() for z in zs]
+    sched = O.ddpm_schedules(1e-4, 0.02, n_T)
+    PD = {"nn_model." + k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        x32 = O.ddpm_sample(PD, sched, n_T, 4, xT, zc, w, steps=steps).double().numpy()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            x16 = O.ddpm_sample(PD, sched, n_T, 4, xT, zc, w, steps=steps).float().double().numpy()
+    x0 = xT.double().numpy()
+    return {"n": n, "steps": steps, "guide_w": w,
+            "x_mse_vs_oracle32": float(((xg - x32) ** 2).mean()), "oracle_autocast_bf16_mse": float(((x16 - x32) ** 2).mean()),
+            "x_maxabs_vs_oracle32": float(np.abs(xg - x32).max()), "oracle_autocast_bf16_maxabs": float(np.abs(x16 - x32).max()),
+            "moved_power": float(((x32 - x0) ** 2).mean()),
+            "graph_vs_eager_injected_maxabs": float(np.abs(xg - xe).max())}
 
 
 def train3_case(dtype):
@@ -428,6 +512,10 @@ def measure_all():
     out = {"unet32_64": {"bf16": unet_case(torch.bfloat16), "fp16": unet_case(torch.float16), "fp32": unet_case(torch.float32)},
            "ddpm_fwd64": {"bf16": ddpm_case(torch.bfloat16), "fp16": ddpm_case(torch.float16), "fp32": ddpm_case(torch.float32)},
            "f128_b8_bf16_vs_oracle_fp32": f128_case(),
+           "f128_b2_vs_reference": {"fp32": f128_b2_case(torch.float32), "bf16": f128_b2_case(torch.bfloat16)},
+           "f128_b2_band_bf16_vs_reference": f128_b2_band_case(),
+           "cfg2_full_size_b64_bf16_vs_oracle_fp32": cfg2_full_size_case(),
+           "cfg4_sample_f128_n16_bf16_graph_vs_oracle_fp32": sample_f128_case(),
            "train3": {"fp32": train3_case(torch.float32), "bf16": train3_case(torch.bfloat16), "fp16": train3_case(torch.float16)},
            "conv_bn_gelu_kernel_bf16": bn_bwd_kernel_case()}
     return out

@@ -176,3 +176,63 @@ def test_mnist_script_train_and_sample_synthetic(tmp_path):
             assert os.path.isfile(os.path.join(str(tmp_path), f"image_ep{ep}_w{w}.png"))
     sd = torch.load(os.path.join(str(tmp_path), "model_2.pth"), map_location="cpu", weights_only=True)
     assert "nn_model.init_conv.conv1.0.weight" in sd and "sqrtab" in sd
+
+
+@pytest.mark.gpu
+def test_two_rank_cli_train_early_stop_then_generate_end_to_end(tmp_path):
+    """the multi-rank path of the DRIVER itself (new_scripy.py:777-848, 1036-1061 on diffusionmodel_amd/train.py),
+    through the command line, as two gloo ranks on one GPU (DM_DIST_BACKEND=gloo; RCCL refuses two ranks per device):
+    `--mode train --gpus 2` on 20 synthetic images in micro-batches of 4 = FIVE micro-batches per epoch (rank 1 idles in the tail
+    group), ACCUM_STEPS 2, an early stop in the second epoch (patience 1, min_delta 10) — every rank must leave (no rank waits in a
+    collective), only rank 0 writes, the ranks' parameters are identical at exit, the checkpoint loads in a single process; then
+    `--mode generate --gpus 2 --seed 11` == the single-process `--mode generate --seed 11` of the same checkpoint."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import subprocess
+    env = dict(os.environ, DM_DIST_BACKEND="gloo", DM_DEVICE_GUARD="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    save, samp = str(tmp_path / "ckpt") + "/", str(tmp_path / "samples") + "/"
+    size = ["--img_size", "64", "--n_feat", "32", "--n_T", "8", "--batch_size", "4", "--bottleneck_k", "4", "--dtype", "float32",
+            "--save_dir", save, "--sample_dir", samp]
+    script = os.path.join(ROOT, "new_scripy.py")
+    r = subprocess.run([sys.executable, script, "--mode", "train", "--gpus", "2", "--epochs", "4", "--accum_steps", "2", "--patience", "1",
+                        "--min_delta", "10", "--n_train", "20", "--n_val", "8", "--guide_scales", "2"] + size,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = r.stdout                                  # rank 0's stdout; rank 1's goes to stderr (parallel.launch_ranks)
+    assert "epoch 0:" in out and "epoch 1:" in out and "epoch 2:" not in out, out[-2000:]           # stopped in the second epoch
+    assert "Early stopping triggered" in out and "parameters identical on 2 ranks" in out, out[-2000:]
+    assert "Saved" not in r.stderr and "epoch 0:" not in r.stderr                                    # rank 1 wrote and said nothing
+    assert out.count("Saved best checkpoint") == 1 and os.path.isfile(save + "best_model.pt") and os.path.isfile(save + "best_model_early.pt")
+    assert os.path.isfile(save + "img_ep0_w2.0.png") and os.path.isfile(save + "metrics/metrics_ep0.json")
+    final = save + "ckpt_ep3.pt"                                                                     # the final save of :931
+    assert os.path.isfile(final)
+    ck = torch.load(final, map_location="cpu", weights_only=True)
+    # 5 micro-batches per epoch, G = 2: steps cover (0,1) (2,3) (4,idle) -> 3 optimiser steps per epoch, 2 epochs
+    assert float(ck["optimizer_state_dict"]["state"][0]["step"]) == 6.0 and len(ck["metrics"]["train_loss"]) == 2
+    import new_scripy as ns
+    from diffusionmodel_amd import Cfg
+    saved = {k: getattr(Cfg, k) for k in ("IMG_SIZE", "N_FEAT", "N_T", "BOTTLENECK_K", "DTYPE")}
+    try:
+        Cfg.IMG_SIZE, Cfg.N_FEAT, Cfg.N_T, Cfg.BOTTLENECK_K, Cfg.DTYPE = 64, 32, 8, 4, "float32"
+        d1 = ns.build_model(4, "cuda:0")
+        d1.load_state_dict(ck["model_state_dict"])                                                   # loads single-process
+    finally:
+        for k, v in saved.items():
+            setattr(Cfg, k, v)
+    imgs = {}
+    for tag, extra in (("two", ["--gpus", "2"]), ("one", [])):
+        sdir = str(tmp_path / ("gen_" + tag)) + "/"
+        g = subprocess.run([sys.executable, script, "--mode", "generate", "--ckpt", final, "--samples", "2", "--guide_scales", "2", "--no_eval",
+                            "--seed", "11", "--save_raw"] + extra + size[:-1] + [sdir],
+                           capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert g.returncode == 0, g.stdout[-2000:] + g.stderr[-3000:]
+        runs = [d for d in os.listdir(sdir) if d.startswith("samples_")]
+        assert len(runs) == 1 and "guide scale 2.0: wrote" in g.stdout and "wrote" not in g.stderr
+        d = os.path.join(sdir, runs[0])
+        assert os.path.isfile(os.path.join(d, "samples_g2.0.png")) and all(os.path.isfile(os.path.join(d, f"class{i}_s{k}_g2.0.png")) for i in range(4) for k in (0, 1))
+        imgs[tag] = torch.load(os.path.join(d, "samples_g2.0.pt"), weights_only=True)
+    assert imgs["two"].shape == (8, 3, 64, 64) and torch.isfinite(imgs["two"]).all()
+    err = (imgs["two"] - imgs["one"]).abs().max().item()
+    assert err <= 2e-5 * 8, err                     # 8 steps; per step only the split-K summation order of a few layers follows the batch size

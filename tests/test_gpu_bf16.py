@@ -126,10 +126,10 @@ def test_benchmark_width_f128_against_the_reference_fixture_bf16_and_fp32():
         assert m["eps_mse_vs_ref64"] <= MARGIN * m["ref_autocast_bf16_mse"]
         assert m["eps_maxabs_vs_ref64"] <= 1.5 * m["ref_autocast_bf16_maxabs"]
         assert abs(m["loss"] - m["loss_ref64"]) <= 3 * _projection_noise(m["ref_autocast_bf16_mse"], m["probe_power"], m["n_elements"])
-        # one rounding-noise realisation against another at B = 2: the same build measured 0.046 .. 0.099 on the worst child (ca3 / down3:
-        # cancellation-heavy gate gradients) when only the fp32 summation order of the split-K layers changed; the reference's own
-        # autocast run sits at 0.046 / 0.091 (eval / train)
-        assert worst <= max(2.0 * worst_ref, 0.05), (mode, m["grad_norm_rel_err"])
+        # the reference's own autocast run sits at 0.046 / 0.091 (eval / train).  r03 widened this bar to 2x after a build whose
+        # in-kernel split-K fold added the partials in ARRIVAL order measured 0.046 .. 0.099 on the worst child (ca3 / down3:
+        # cancellation-heavy gate gradients) from run to run; the fold has a fixed order since, so the bar is the stated one again
+        assert worst <= max(MARGIN * worst_ref, 0.02), (mode, m["grad_norm_rel_err"])
 
 
 def test_cfg2_full_size_b64_train_forward_against_the_oracle():
@@ -263,3 +263,17 @@ def test_loss_scaler_skips_overflowed_steps_and_adapts_the_scale():
     off = D.DmGradScaler(enabled=False)
     t = torch.ones(1, device="cuda:0")
     assert off.scale(t) is t and off.get_scale() == 1.0 and off.state_dict() == {}
+
+
+def test_cfg4_sampling_at_the_benchmark_width_bf16_graph_against_the_oracle():
+    """the BENCHMARKED sampler (bf16, n_feat = 128, hipGraph replay, encoder de-dup, broadcast skip tensors,
+    folded BatchNorm) compared with the oracle, not only with itself: three CFG steps (new_scripy.py:441-477) at n = 16, w = 2 on
+    the graph's own Philox noise (regenerated and injected into the float32 oracle): x MSE <= 1.25x the oracle's autocast(bfloat16)
+    MSE; the eager run with that noise injected equals the replayed graph."""
+    m = PL.sample_f128_case()
+    print(f"cfg-4 sampler F=128 n=16 bf16 graph, 3 steps: x MSE {m['x_mse_vs_oracle32']:.3e} vs oracle-autocast {m['oracle_autocast_bf16_mse']:.3e}; "
+          f"max-abs {m['x_maxabs_vs_oracle32']:.3e} vs {m['oracle_autocast_bf16_maxabs']:.3e}; moved power {m['moved_power']:.3e}; "
+          f"graph vs eager-injected {m['graph_vs_eager_injected_maxabs']:.1e}")
+    assert m["x_mse_vs_oracle32"] <= MARGIN * m["oracle_autocast_bf16_mse"]
+    assert m["x_maxabs_vs_oracle32"] <= 1.5 * m["oracle_autocast_bf16_maxabs"]
+    assert m["graph_vs_eager_injected_maxabs"] <= 1e-6           # same kernels, same noise: the graph only removes the host

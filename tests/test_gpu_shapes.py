@@ -81,6 +81,47 @@ def test_nfeat_multiple_of_16_not_32(nf):
     assert int(sd["down1.channel_compress.1.num_batches_tracked"]) == 1
 
 
+def test_nfeat_48_train_step_as_a_launch_plan():
+    """the padded compress branch of n_feat % 32 == 16 models mirrored its parameters with torch copy_ —
+    memcpy nodes under stream capture, which a launch plan refuses — so the default path of TrainEngine / new_scripy (use_plan)
+    could not be built for them.  Now the branch moves its data with library launches: the plan builds, holds no torch copy
+    kernel, and three replays train like three eager steps (FusedAdamW included)."""
+    import diffusionmodel_amd as D
+
+    def make():
+        torch.manual_seed(11)
+        net = D.ContextUnet(3, 48, 4, bottleneck_k=4, dtype=torch.float32)
+        ddpm = D.DDPM(net, (1e-4, 0.02), 1, DEV, drop_prob=0.0)
+        ddpm.train()
+        ddpm.rng_seed = 5
+        return ddpm, D.FusedAdamW(ddpm.parameters(), lr=1e-3, weight_decay=1e-5, max_grad_norm=1.0)
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 64, 64, generator=g).to(DEV)
+    c = torch.randint(0, 4, (2,), generator=g).to(DEV)
+    am = torch.ones(2, 64, 64).to(DEV)
+    da, oa = make()
+    la = []
+    for _ in range(3):
+        oa.zero_grad()
+        loss = da(x, c, am)
+        loss.backward()
+        oa.step()
+        la.append(loss.item())
+    db, ob = make()
+    step = D.GraphedTrainStep(db, ob, x, c, am, mode="plan")
+    foreign = step.plan.foreign_kernels()
+    assert not any("copy" in nm.lower() for nm in foreign), foreign
+    lb = [step(x, c, am).item() for _ in range(3)]
+    for a, b in zip(la, lb):
+        assert abs(a - b) <= 2e-4 * max(abs(a), 1e-3), (la, lb)
+    assert lb[-1] < lb[0]
+    sa, sb = da.state_dict(), db.state_dict()
+    k = "nn_model.down1.channel_compress.1.running_mean"
+    assert sa[k].shape == (12,) and float((sa[k] - sb[k]).abs().max()) < 1e-4 * max(1.0, float(sa[k].abs().max()))
+    assert int(sa["nn_model.down1.channel_compress.1.num_batches_tracked"]) == int(sb["nn_model.down1.channel_compress.1.num_batches_tracked"]) == 3
+
+
 def test_hidden_2x2_at_256_k8():
     _compare(32, 256, 8, 1)
 

@@ -491,3 +491,51 @@ def test_grad_scaler_surface_matches_torch_and_is_inert_when_disabled():
     with pytest.raises(D.DmError):
         D.ContextUnet(3, 32, 4, dtype=torch.float64)
     assert D.ContextUnet(3, 32, 4, dtype=torch.float16).compute_dtype == torch.float16
+
+
+def test_drop_in_scripts_export_every_public_name_of_the_reference_modules():
+    """VERDICT r03 missing #4: `from new_scripy import ResConvBlock` etc. must resolve.  The lists are the top-level `class` / `def`
+    names of the reference files (new_scripy.py:22-1111, MNIST_script.py:31-303)."""
+    import importlib
+    ns = importlib.import_module("new_scripy")
+    for name in ("Cfg", "CoordAttn", "SEBlock", "LocalEnhancer", "ResConvBlock", "UnetDown", "UnetUp", "EmbedFC", "ContextUnet", "ddpm_schedules",
+                 "DDPM", "CrackDataset", "save_samples", "gen_and_save", "EarlyStop", "create_loaders", "train_model", "gen_samples", "ImageMetrics"):
+        assert hasattr(ns, name), name
+    mn = importlib.import_module("MNIST_script")
+    for name in ("ResidualConvBlock", "UnetDown", "UnetUp", "EmbedFC", "ContextUnet", "ddpm_schedules", "DDPM", "train_mnist"):
+        assert hasattr(mn, name), name
+    import diffusionmodel_amd as D
+    assert ns.ResConvBlock is D.ResConvBlock and mn.UnetDown is not ns.UnetDown          # the MNIST blocks are the ancestor's own
+
+
+def test_create_loaders_is_the_reference_split_and_shards_by_rank():
+    """new_scripy.py:622-657: StratifiedShuffleSplit(n_splits=1, test_size=val_split, random_state=42) over dataset.samples[i][2];
+    train shuffled, validation in order, no drop_last.  With world = 2 the two ranks' train loaders partition the micro-batches of ONE
+    permutation (train.StridedBatchSampler)."""
+    import numpy as np
+    import new_scripy as ns
+    from sklearn.model_selection import StratifiedShuffleSplit
+
+    class DS(torch.utils.data.Dataset):
+        def __init__(self):
+            self.samples = [(f"img{i}", None, i % 3) for i in range(50)]
+
+        def __len__(self):
+            return len(self.samples)
+
+        def __getitem__(self, i):
+            return torch.full((1,), float(i)), self.samples[i][2], torch.zeros(1)
+    ds = DS()
+    labels = [s[2] for s in ds.samples]
+    tr_ref, va_ref = next(StratifiedShuffleSplit(n_splits=1, test_size=0.2, random_state=42).split(np.zeros(50), labels))
+    tl, vl = ns.create_loaders(ds, 8, val_split=0.2, num_workers=0, pin_mem=False)
+    assert list(tl.dataset.indices) == list(tr_ref) and list(vl.dataset.indices) == list(va_ref)
+    assert [int(v) for b in vl for v in b[0].reshape(-1)] == [int(i) for i in va_ref]                    # validation in order
+    assert sorted(int(v) for b in tl for v in b[0].reshape(-1)) == sorted(int(i) for i in tr_ref)        # short last batch kept
+    parts = []
+    for r in range(2):
+        t2, _ = ns.create_loaders(ds, 8, val_split=0.2, num_workers=0, pin_mem=False, rank=r, world=2, seed=5)
+        t2.batch_sampler.set_epoch(3)
+        parts.append([[int(v) for v in b[0].reshape(-1)] for b in t2])
+    assert len(parts[0]) == 3 and len(parts[1]) == 2                                                     # 40 samples -> 5 micro-batches
+    assert sorted(v for p_ in parts for b in p_ for v in b) == sorted(int(i) for i in tr_ref)
