@@ -16,7 +16,7 @@ DEFAULT_CONV_VARIANT = 5      # what libdm_amd.so starts with (igemm.hip g_varia
 DM_F32, DM_BF16, DM_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 
-vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+vp, i32, i64, u64, f32, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_uint32
 
 
 class DmConv(C.Structure):
@@ -115,6 +115,8 @@ _PROTOS = {
     "dm_scaler_update": [vp, vp, vp, f32, f32, i32],
     "dm_randn_dev": [vp, i64, u64, vp],
     "dm_pack_multi": [vp, vp, vp, i32],
+    "dm_allreduce_bucket": [vp, i64, i32, vp],
+    "dm_debug_poison_lds": [u32],
     "dm_plan_marker": [i32],
     "dm_plan_run": [vp, i32, i32],
     "dm_plan_run_timed": [vp, i32, i32, C.c_char_p],
@@ -123,7 +125,9 @@ _PROTOS = {
 _NO_STREAM = {"dm_last_conv_path": ([], i32), "dm_last_wgrad_path": ([], i32), "dm_get_conv_variant": ([], i32), "dm_set_conv_tap4": ([i32], i32), "dm_set_conv_persist": ([i32], i32), "dm_set_conv_packtap": ([i32], i32), "dm_last_conv_persistent": ([], i32), "dm_set_wgrad_pw": ([i32, i32, i32], i32), "dm_set_wgrad_tap4": ([i32], i32), "dm_set_wgrad_skinny": ([i32], i32), "dm_set_splitk_inkernel": ([i32], i32), "dm_set_workspace": ([vp, i64], i32), "dm_set_conv_variant": ([i32], i32), "dm_set_wgrad_variant": ([i32], i32), "dm_version": ([], i32), "dm_last_error": ([], C.c_char_p), "dm_colstat_blocks": ([i32], i32),
               "dm_plan_from_graph": ([vp, C.POINTER(vp)], i32), "dm_plan_info": ([vp, C.POINTER(i32)], i32),
               "dm_plan_segment_marker": ([vp, i32], i32), "dm_plan_op_name": ([vp, i32, C.c_char_p, i32], i32),
-              "dm_plan_destroy": ([vp], i32)}
+              "dm_plan_destroy": ([vp], i32),
+              "dm_comm_load": ([C.c_char_p], i32), "dm_comm_unique_id": ([vp], i32), "dm_comm_init": ([C.POINTER(vp), i32, i32, vp], i32),
+              "dm_comm_destroy": ([vp], i32)}
 
 EXPORTED = sorted(list(_PROTOS) + list(_NO_STREAM))
 
@@ -305,9 +309,17 @@ def dt(t_or_dtype):
     raise DmError(f"unsupported dtype {d}: the HIP path computes in float32, bfloat16 or float16")
 
 
+POISON_CALLS = [0]
+POISON_LDS = [None]       # tests: a 32-bit pattern -> every library call is preceded by dm_debug_poison_lds(pattern) on the same stream
+
+
 def call(name, *args):
     """Invoke an entry point on the current stream; raise DmError on failure."""
     lib = load()
+    if POISON_LDS[0] is not None and name != "dm_debug_poison_lds":
+        POISON_CALLS[0] += 1
+        if lib.dm_debug_poison_lds(int(POISON_LDS[0]), _stream()) != 0:
+            raise DmError("dm_debug_poison_lds: " + lib.dm_last_error().decode())
     rc = getattr(lib, name)(*args, _stream())
     if rc != 0:
         raise DmError(f"{name} failed (rc={rc}): {lib.dm_last_error().decode()}")

@@ -7,6 +7,14 @@
 #ifndef DM_HALO_DMA_POS
 #define DM_HALO_DMA_POS 567
 #endif
+// 1: the per-tile halo kernel keeps pixel fragments in registers across the three taps of a halo column offset where the wave's
+// pixels are 4 rows x 16 columns (TW = 16; igemm_halo.hip, REUSE): 108 instead of 144 ds_read_b128 per chunk and wave.  Measured r04
+// (profiles/r04_ab_same_box.txt): 16x16 512->512 forward 65.0 / 66.2 / 65.7 us without, 63.7 / 65.5 / 64.1 us with — a quarter of the
+// fragment reads buys 1.8 %, i.e. the LDS reads are not what the k-loop waits for.  Off: the tap order changes the fp32 summation
+// order (the persistent form would have to follow for its bit-identity test) for 0.015 ms per train step.
+#ifndef DM_HALO_REUSE
+#define DM_HALO_REUSE 0
+#endif
 #include <type_traits>
 #include "common.h"
 

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
     // ([0 A 0][0 B 0][0 C 0][0 D 0], 10 columns apiece): rows stay multiples of 8 pixels, a wave (64 pixels) is one image
     constexpr int TH = TW == 8 ? 8 : 256 / TW, HS = TW == 8 ? 40 : TW + 8, HR = TH + 2, NP = HR * HS / 8;
     static_assert(NP <= HALO_PIECES, "halo does not fit");
+    constexpr bool REUSE = DM_HALO_REUSE && TW == 16 && DM_HALO_DMA_POS != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [halo 0][halo 1][w 0][w 1][w 2]
     char* const sW = smem + 2 * HALO_BYTES;
 
@@ -142,10 +143,64 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
 
 #pragma unroll
     for (int i = 0; i < 7; ++i) issue_h(i, c_lo, 0);
-    issue_w(0, c_lo, 0);
-    issue_w(1, c_lo, 1);
+    issue_w(REUSE ? (FLIP ? 8 : 0) : 0, c_lo, 0);          // the weights of steps 0 and 1 (REUSE: column-major steps, see the loop)
+    issue_w(REUSE ? (FLIP ? 5 : 3) : 1, c_lo, 1);
     int hdelta = HALO_BYTES;
-    {
+    if constexpr (REUSE) {
+        // r04: pixel fragments kept in registers across the three taps of a halo COLUMN offset.  The wave's pixels are 4 image rows x 16
+        // columns (TW = 16: rows 4 wm4 .. 4 wm4 + 3), so for a fixed column offset hx the taps hy = 0, 1, 2 read halo rows j = hy .. hy + 3
+        // of ONE six-row strip: step (hx, 0) reads rows 0..3, (hx, 1) adds row 4, (hx, 2) adds row 5 — 6 + 6 pixel-fragment reads per
+        // column offset instead of 24 (weight fragments unchanged: 8 per tap): 108 instead of 144 ds_read_b128 per chunk and wave.
+        // Steps walk the taps column-major (hx = s / 3, hy = s % 3); the weight of halo offset (hy, hx) is tap hy * 3 + hx, or its mirror
+        // image when FLIP (input gradient).  Same DMA schedule, ring stage = step % 3.  The summation order over the taps differs from
+        // the row-major loop: results agree to fp32 rounding, integer data exactly.
+        u32x4 fbr[2][6];
+        auto wtap = [](int st) { const int hx = st / 3, hy = st % 3; return FLIP ? (2 - hy) * 3 + (2 - hx) : hy * 3 + hx; };
+        for (int chunk = c_lo; chunk < nchunks; ++chunk) {
+            const int nbuf = (chunk - c_lo + 1) & 1;
+#pragma unroll
+            for (int st = 0; st < 9; ++st) {
+                if (st >= 1 && st <= 7) wait_vmcnt<3>();
+                else wait_vmcnt<2>();
+                __builtin_amdgcn_s_barrier();
+                const int s2 = (st + 2) % 9;
+                const int hx = st / 3, hy = st % 3;
+                const char* sWs = sW + (st % 3) * WSTAGE;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+                    u32x4 fa[4];
+                    if (hy == 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) fbr[sub][j] = *(const u32x4*)(smem + hoff[hx][sub][0] + (j * HS + hx) * ROWB);
+                    } else {
+                        fbr[sub][3 + hy] = *(const u32x4*)(smem + hoff[hx][sub][0] + ((3 + hy) * HS + hx) * ROWB);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) fa[nt] = *(const u32x4*)(sWs + woff[sub][nt]);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        {
+                            constexpr int G0 = DM_HALO_DMA_POS / 100, G1 = DM_HALO_DMA_POS / 10 % 10, G2 = DM_HALO_DMA_POS % 10;
+                            const int g = sub * 4 + nt;
+                            const int cw = chunk + (st + 2 >= 9 ? 1 : 0);
+                            if (g == G0 || g == G1 || g == G2) __builtin_amdgcn_sched_barrier(0);
+                            if (g == G0) issue_w1(0, wtap(s2), cw, s2 % 3);
+                            if (g == G1) issue_w1(1, wtap(s2), cw, s2 % 3);
+                            if (g == G2 && st < 7) issue_h(st, chunk + 1, nbuf);
+                            if (g == G0 || g == G1 || g == G2) __builtin_amdgcn_sched_barrier(0);
+                        }
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) Mma<T>::run(fa[nt], fbr[sub][mt + hy], acc[nt][mt]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) hoff[kx][sub][0] += hdelta;
+            hdelta = -hdelta;
+        }
+    } else {
         for (int chunk = c_lo; chunk < nchunks; ++chunk) {
             const int nbuf = (chunk - c_lo + 1) & 1;
 #pragma unroll

@@ -33,6 +33,38 @@ extern "C" int dm_set_workspace(void* ws, int64_t bytes) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// dm_debug_poison_lds: one workgroup per CU fills all 160 KiB of that CU's LDS with `pattern` (test infrastructure for the residue
+// audit: LDS survives a kernel boundary, so a kernel that reads bytes it did not write computes on whatever ran before it — its own
+// benign residue when a process has the GPU to itself, a stranger's data when it does not.  With NaN bit patterns in every word
+// beforehand, such a read turns an exact-integer result into NaN.)  A workgroup that holds 160 KiB has a CU to itself; every
+// workgroup waits ~20 us after its fill, so the `n_cu` workgroups of the launch are resident together, i.e. on `n_cu` different CUs.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void poison_lds_kernel(uint32_t pattern) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
+    for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) lds_all[i] = pattern;
+    __syncthreads();
+    for (int i = 0; i < 200; ++i) __builtin_amdgcn_s_sleep(127);       // ~ 200 x 127 x 64 cycles / 2.4 GHz = 0.7 ms upper bound; s_sleep is a hint
+}
+}  // namespace
+
+extern "C" int dm_debug_poison_lds(uint32_t pattern, dm_stream_t stream) {
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+        hipError_t e = hipFuncSetAttribute((const void*)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { ncu = 0; dm_set_error("dm_debug_poison_lds: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(ncu), dim3(256), 160 * 1024, (hipStream_t)stream, pattern);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { dm_set_error("dm_debug_poison_lds: %s", hipGetErrorString(e)); return (int)e; }
+    return DM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Launch plans (dm_plan_*): replay of a captured step as PLAIN stream launches issued from C.
 //
 // The train step is ~800 launches; issued from Python one by one the host needs 12-15 ms per step, and a replayed hipGraph

@@ -392,6 +392,46 @@ class OverlappedGradReducer:
         return 4 * (int(self.flat.numel()) + int(self._small_total))
 
 
+class CAbiComm:
+    """The C ABI's own collective (include/dm_amd.h: dm_comm_unique_id / dm_comm_init / dm_allreduce_bucket / dm_comm_destroy —
+    RCCL bound by dlopen inside libdm_amd.so), for hosts that bring no torch.distributed.  `exchange(id_bytes_or_None) -> id_bytes`
+    is the caller's out-of-band channel for the 128-byte unique id (rank 0 passes its id in, every rank gets rank 0's back); with
+    world == 1 it is not needed.  all_reduce() is an in-place SUM on torch's current stream, asynchronous like a kernel launch."""
+
+    def __init__(self, rank=0, world=1, exchange=None):
+        import ctypes as C
+        from . import _lib as L
+        lib = L.load()
+        uid = C.create_string_buffer(128)
+        if rank == 0 and lib.dm_comm_unique_id(uid) != 0:
+            raise DmError("dm_comm_unique_id: " + lib.dm_last_error().decode())
+        if world > 1:
+            if exchange is None:
+                raise DmError("CAbiComm: world > 1 needs an `exchange` callable that carries rank 0's 128-byte id to every rank")
+            uid = C.create_string_buffer(bytes(exchange(uid.raw if rank == 0 else None)), 128)
+        self._h, self._lib, self.rank, self.world = C.c_void_p(), lib, rank, world
+        if lib.dm_comm_init(C.byref(self._h), int(world), int(rank), uid) != 0:
+            raise DmError("dm_comm_init: " + lib.dm_last_error().decode())
+
+    def all_reduce(self, t):
+        from . import ops
+        if not t.is_contiguous():
+            raise DmError("CAbiComm.all_reduce: contiguous tensors only")
+        ops.call("dm_allreduce_bucket", ops.ptr(t), t.numel(), ops.dt(t), self._h)
+        return t
+
+    def close(self):
+        if self._h:
+            self._lib.dm_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                         # noqa: BLE001 — interpreter shutdown
+            pass
+
+
 def wait_ranks(procs, poll=0.2):
     """Wait for the child ranks; when one exits non-zero the others are terminated (they would otherwise sit in a collective
     until the RCCL timeout).  Returns the list of exit codes."""

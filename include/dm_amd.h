@@ -420,6 +420,28 @@ int dm_plan_run_timed(void* plan, int seg_first, int seg_last, const char* subst
 int dm_plan_timed_results(void* plan, float* ms_out, int32_t* op_out, int cap, int32_t* n_out, dm_stream_t stream);
 int dm_plan_destroy(void* plan);
 
+/* Test aid (LDS residue audit): fills all 160 KiB of EVERY CU's LDS with `pattern` (one 160-KiB workgroup per CU).
+ * Launched before a kernel under test with a NaN bit pattern, it turns any read of LDS bytes that kernel did not write itself into
+ * NaNs in an exact-integer result.  Not used by the product path.                                                               */
+int dm_debug_poison_lds(uint32_t pattern, dm_stream_t stream);
+
+/* ---- data-parallel collective (allreduce_bucket(ptr, n, dtype, comm, stream)) -----------------------------
+ * The reference has no distributed code; what the collective must preserve is its gradient accumulation (new_scripy.py:786,
+ * 795-803): rank == micro-batch, gradients SUMMED over the ranks, 1/world applied by the optimiser (hyper9[6] of dm_adamw),
+ * clipping on the reduced gradient.  One process per GPU; RCCL over xGMI; librccl.so is bound at run time (dlopen): the path given
+ * to dm_comm_load, else $DM_RCCL_LIB, else a librccl the process has already mapped (a torch process: torch's own), else the
+ * loader's default search.  A binder that owns no torch.distributed drives data parallelism with these five calls alone:
+ *   rank 0: dm_comm_unique_id(id) -> ships the 128 bytes to the other ranks by its own means (file, socket, MPI ...)
+ *   every rank: dm_comm_init(&comm, world, rank, id); per step and gradient bucket: dm_allreduce_bucket(grad + lo, n, DM_F32, comm, s)
+ *   — in place, SUM, asynchronous on `s` (ordered like a kernel launch on that stream) — ; dm_comm_destroy(comm).
+ * Errors: DM_EUNSUPPORTED when librccl.so cannot be found / lacks the nccl* entry points, -1000 - ncclResult_t for an RCCL failure
+ * (its text in dm_last_error()).                                                                                              */
+int dm_comm_load(const char* librccl_path);
+int dm_comm_unique_id(void* id128);                                                     /* out: 128 bytes (ncclUniqueId) */
+int dm_comm_init(void** comm_out, int world, int rank, const void* id128);
+int dm_allreduce_bucket(void* ptr, int64_t n, int dtype, void* comm, dm_stream_t stream);
+int dm_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

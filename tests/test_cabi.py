@@ -31,6 +31,8 @@ def ctype_of(arg):
         return C.c_int64
     if "uint64_t" in arg:
         return C.c_uint64
+    if "uint32_t" in arg:
+        return C.c_uint32
     if arg.startswith("float"):
         return C.c_float
     if arg.startswith("int"):
@@ -99,3 +101,34 @@ def test_product_refuses_cpu_tensors(lib):
     import torch
     with pytest.raises(lib.DmError):
         lib.require_device(torch.zeros(1))
+
+
+def test_collective_entry_points_fail_loudly_without_rccl(lib):
+    """dm_allreduce_bucket(ptr, n, dtype, comm, stream) is part of the C ABI (include/dm_amd.h, comm.hip binds librccl.so
+    at run time).  No GPU here: a bad library path is refused with DM_EUNSUPPORTED and a message, a null communicator with DM_EINVAL."""
+    h = lib.load()
+    assert h.dm_comm_load(b"/nonexistent/librccl.so") == -2 and b"librccl" in h.dm_last_error()
+    assert h.dm_allreduce_bucket(C.c_void_p(16), 4, 0, None, None) == -1
+    assert h.dm_comm_destroy(None) == 0
+
+
+@pytest.mark.gpu
+def test_c_abi_allreduce_bucket_world_1_over_rccl():
+    """The collective of the C ABI on one rank (a one-GPU box): unique id -> communicator -> in-place SUM all-reduce of fp32 and bf16
+    buckets on torch's current stream (with one rank the sum is the input) -> destroy.  N > 1 needs one GPU per rank (RCCL refuses two
+    ranks on a device); the multi-rank arithmetic is covered through torch.distributed (tests/test_host_logic.py, gloo)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from diffusionmodel_amd.parallel import CAbiComm
+    comm = CAbiComm(rank=0, world=1)
+    g = torch.randn(1 << 20, device="cuda:0")
+    want = g.clone()
+    comm.all_reduce(g)
+    comm.all_reduce(g[1024:4096])
+    h = torch.randn(4096, device="cuda:0").bfloat16()
+    hw = h.clone()
+    comm.all_reduce(h)
+    torch.cuda.synchronize()
+    assert torch.equal(g, want) and torch.equal(h, hw)
+    comm.close()

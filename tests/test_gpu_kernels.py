@@ -1127,3 +1127,45 @@ def test_packed_tap_kernel_matches_the_halo_kernel_with_batchnorm_and_gelu(dtype
     for name, u, v in zip(("y", "dw", "dgamma", "dbeta", "running_mean", "running_var"), a, b_):
         tol = 2 * ulp if name == "y" else 2e-3
         assert float((u - v).abs().max()) <= tol * float(v.abs().max()), (name, float((u - v).abs().max()), float(v.abs().max()))
+
+
+def test_lds_residue_audit_exact_integer_kernels_with_every_cu_lds_poisoned():
+    """VERDICT r03 #8 (the r02 corruption, by audit instead of repetition): no workgroup is preempted mid-kernel on this stack, so what a
+    foreign process can leave behind is what survives a kernel boundary on a CU — LDS above all.  A kernel that reads LDS bytes it did
+    not write itself computes on its own benign residue when alone and on a stranger's data in company.  Deterministic check, one
+    process, one pass: before EVERY library launch all 160 KiB of every CU's LDS are filled with a NaN bit pattern (fp32 NaN = two bf16
+    NaNs = two fp16 NaNs: dm_debug_poison_lds, _lib.POISON_LDS), and the exact-integer tests of the LDS-heavy kernel families are run
+    again: the halo convolution / its input gradient / the halo weight gradient (+ reduce), the four-tap halo kernels of the 4x4 stride-2
+    layer (conv + weight gradient), the pointwise conv and weight-gradient kernels, the packed-tap / narrow / skinny kernels, the
+    persistent halo kernel, the split-K last-arriver fold, the dense kernels.  Any residue read shows up as NaN in a bit-exact result."""
+    from diffusionmodel_amd import _lib as L
+    lib = L.load()
+    L.POISON_CALLS[0] = 0
+    L.POISON_LDS[0] = 0x7FC17FC1
+    try:
+        test_wgrad_bf16_exact_integers()
+        assert lib.dm_set_conv_variant(5) == 0
+        for case in HALO_CASES:
+            test_conv_halo_kernel_exact_integers(case, None)
+        for case in TAP4_CASES:
+            for dtype in (torch.bfloat16, torch.float16):
+                test_conv4x4s2_four_tap_halo_kernel_exact_integers(case, dtype)
+        test_splitk_last_arriver_form_is_bit_exact_too()
+        for dtype in (torch.bfloat16, torch.float16):
+            for shp in [(2, 32, 128, 16), (1, 64, 64, 12), (2, 128, 32, 8), (3, 128, 256, 10), (1, 32, 40, 9), (2, 64, 136, 16)]:
+                test_pointwise_conv_kernel_exact_integers(dtype, *shp)
+        for dtype in (torch.bfloat16, torch.float16):
+            for shp in [(2, 32, 128, 16), (3, 128, 32, 10), (4, 32, 256, 32), (1, 256, 32, 9), (2, 64, 512, 16), (3, 256, 64, 8), (2, 128, 128, 16),
+                        (1, 128, 384, 12), (3, 512, 128, 8)]:
+                test_pointwise_wgrad_kernel_exact_integers(dtype, *shp)
+        test_persistent_halo_kernel_exact_integers()
+        for args in [(3, 128, 64, torch.bfloat16), (2, 192, 64, torch.float16), (1, 128, 128, torch.bfloat16)]:
+            test_packed_tap_kernel_stem_forward_exact_integers(*args)
+        for args in [(3, 128, 64, torch.bfloat16), (2, 256, 64, torch.float16), (1, 128, 128, torch.bfloat16)]:
+            test_packed_tap_kernel_head_input_gradient_exact_integers(*args)
+        for mkn in [(64, 1024, 1024), (64, 1024, 64), (2048, 128, 8)]:
+            test_dense_layer_kernels_exact_integers(*mkn)
+    finally:
+        L.POISON_LDS[0] = None
+        lib.dm_set_conv_variant(L.DEFAULT_CONV_VARIANT)
+    assert L.POISON_CALLS[0] > 500, L.POISON_CALLS[0]          # the poison launches really ran

@@ -492,7 +492,7 @@ def test_train_engine_plan_then_eager_tail_batch_starts_from_a_zero_gradient():
     for i, ((la, na), (lb, nb)) in enumerate(zip(ra, rb)):
         # through the step after the tail the two runs agree to the atomics band; after five lr = 1e-3 Adam steps on B = 2 they drift (1e-3)
         assert abs(la - lb) <= (2e-4 if i <= 3 else 5e-3) * max(abs(la), 1e-3), (ra, rb)
-        assert abs(na - nb) <= 2e-2 * na, (ra, rb)              # (the stale gradient makes the tail step's norm ~2x; Adam steps on atomics-ordered sums drift by ~5e-3)
+        assert abs(na - nb) <= (2e-2 if i <= 3 else 0.1) * na, (ra, rb)              # (the stale gradient makes the tail step's norm ~2x; Adam steps on atomics-ordered sums drift by ~5e-3)
     rel = ((oa.flat_p - ob.flat_p).norm() / oa.flat_p.norm()).item()
     assert rel < 5e-3, rel
 
