@@ -576,96 +576,7 @@ struct WgHP {
     const char* dy; const char* in1; const char* in2; float* dw; float* dbias; float* ws;
     int B, Hi, Wi, C1, C2, N, ldy, ldw;
     int ntiles, nchunks, blocks, splits, tiles_per_split;
-    // r04, in-kernel pairwise fold of the pixel splits (see wgrad_tree_fold): `fold_levels` levels of a binary tree over the splits of a
-    // block run inside the launch; fold_levels == 0: every split parks its register image for wgrad_reduce_kernel (r01 .. r03)
-    int fold_levels, nodes_per_block;
-    long long counters_off;                      // byte offset of the arrival counters from `ws` (they sit at the workspace's tail)
 };
-// the fold's scalars are read from the kernarg segment where they are used (an opaque constant-address-space pointer: s_load at the
-// flush, nothing hoisted): kept as ordinary kernel arguments they stay live through the tile loop, the kernel runs out of SGPRs, the
-// overflow lands in VGPR lanes and the 144 accumulators start to spill — a scratch reload inside the loop waits on vmcnt, i.e. on the
-// next tile's DMA (r04: 97 scratch instructions, 30 of them between the MFMAs, with the three fields read from `p`)
-typedef const __attribute__((address_space(4))) WgHP* WgKernargP;
-__device__ __forceinline__ WgKernargP wg_kernarg() {
-    const __attribute__((address_space(4))) char* kp = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));
-    return (WgKernargP)kp;
-}
-
-// ---- in-kernel fold of the pixel splits that share a dw block (r04) ---------------------------------------------------------------
-// Every partial has to leave its CU once, so the 256 x 288 KiB a launch parks in the workspace are not what can be saved; what can is
-// the second launch that reads them back (wgrad_reduce_kernel: 17 - 39 us behind a 62 - 65 us kernel) and half of the parked bytes.
-// A binary tree over the splits of a block, roles by ARRIVAL: of the two workgroups of a node the one whose counter add comes FIRST
-// stores its register image (`sc1`: write-through, out of its XCD's L2), waits for the stores, raises the node's `ready` word and
-// exits; the SECOND polls `ready` (the writer is past its last tile: a bounded wait on a workgroup that is running), loads the image
-// (`sc1` loads), adds it to its registers and goes up a level; the survivor of the root adds into dw itself.  Nobody ever waits for a
-// workgroup that has not been scheduled, so the grid needs no co-residency; a + b == b + a exactly, and the tree is fixed by the split
-// indices, so the result does not depend on who arrives first.  Counters / ready words: DM_WS_COUNTERS tail of the workspace, upper
-// half (the split-K convolutions count in the lower), reset by the second arriver.
-// The images travel as buffer loads / stores with the sc1 cache policy (aux = 16): the lane's offset is one VGPR (16 lane), the image's
-// a scalar — no address registers next to the 144 accumulators, and the compiler sees the loads (its own s_waitcnt placement).  (Built
-// first with inline-asm global_load / global_store sc1 as in the split-K convolution: one address pair per image, 12-image batches
-// tied by "+v" operands — the kernel went from 234 VGPRs to 256 + 64 .. 111 scratch instructions, two of them reloads inside the tile loop.)
-typedef __attribute__((ext_vector_type(4))) unsigned wg_u32x4;
-constexpr int WG_SC1 = 16;
-constexpr int WG_FOLD_MAX_LEVELS = 3;
-constexpr int WG_FOLD_CNT = 8192, WG_FOLD_RDY = 8192 + 4096;          // offsets into dm_g_counters (DM_WS_COUNTERS = 16384 ints)
-
-// returns the index among the survivors of the workgroup that still holds the (partly) folded sum after `levels` levels, -1 for a retired one
-template <int NI, int NT>
-__device__ __forceinline__ int wgrad_tree_fold(f32x4 (&acc)[NI][NT], float* ws, int* counters, char* smem, int block, int split, int splits,
-                                               int levels, int nodes_per_block, int wave, int lane, int tid) {
-    constexpr int NACC = NI * NT;
-    int* role = (int*)(smem + 16384);
-    const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc((void*)ws, 0, 0x7fffffff, WG_SRD);
-    int idx = split, nsurv = splits, level_off = 0;
-    // (straight-line code for the at most WG_FOLD_MAX_LEVELS levels: with a run-time loop around the 36 image loads / stores the
-    //  register allocator spilled a third of the accumulators at the back edge and two loop-invariant lane offsets of the TILE loop)
-#pragma unroll
-    for (int L = 0; L < WG_FOLD_MAX_LEVELS; ++L) {
-        if (L < levels && (idx ^ 1) < nsurv) {                                   // (an odd survivor without a sibling passes through)
-            const int node = block * nodes_per_block + level_off + (idx >> 1);
-            int* cnt = counters + WG_FOLD_CNT + node;
-            int* rdy = counters + WG_FOLD_RDY + node;
-            const int soff = (node * 8 + wave) * NACC * 1024;      // byte offset of this wave's image group in the tree region (< 2^31: <= 256 nodes)
-            __syncthreads();
-            if (tid == 0) *role = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            if (*role == 0) {                                      // first to arrive: park the image, publish, done
-#pragma unroll
-                for (int i = 0; i < NACC; ++i)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wg_u32x4, acc[i / NT][i % NT]), rws, lane * 16, soff + i * 1024, WG_SC1);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) __hip_atomic_store(rdy, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return -1;
-            }
-            if (tid == 0) {                                        // second: the sibling is writing or has written
-                int spins = 0;
-                while (__hip_atomic_load(rdy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(4);
-                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
-                __hip_atomic_store(rdy, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-            static_assert(NACC % 12 == 0, "batches of twelve images");
-#pragma unroll
-            for (int b0 = 0; b0 < NACC; b0 += 12) {               // 12 images (48 VGPRs) in flight next to the accumulators, not all 36
-                wg_u32x4 v[12];
-#pragma unroll
-                for (int i = 0; i < 12; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane * 16, soff + (b0 + i) * 1024, WG_SC1);
-#pragma unroll
-                for (int i = 0; i < 12; ++i) acc[(b0 + i) / NT][(b0 + i) % NT] += __builtin_bit_cast(f32x4, v[i]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (L < levels) {
-            level_off += nsurv >> 1;
-            idx >>= 1;
-            nsurv = (nsurv + 1) >> 1;
-        }
-    }
-    return idx;
-}
 
 // S2 = true: the 4x4 / stride-2 / pad-1 layer, one input-parity class (py, px) per workgroup.  With V(y, x) = X(2y + py, 2x + px) the
 // class's four taps (ky, kx) = (2 jy + 1 - py, 2 jx + 1 - px), j in {0, 1}^2, read V at (qy + jy - py, qx + jx - px): a 2x2-tap layer on a
@@ -881,22 +792,6 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
         bphase = bphase + 1 == p.nchunks ? 0 : bphase + 1;
     }
 
-    // dbias first (the fold below may retire this workgroup): fold the 16 row groups in LDS, then one value per column and workgroup
-    if (want_bias) {
-        __syncthreads();
-        float* sb = (float*)smem;                // [16][128]
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sb[brow * 128 + bcol + e] = bsum[e];
-        __syncthreads();
-        if (tid < 128) {
-            float v = 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v += sb[j * 128 + tid];
-            if (p.splits > 1 && !S2 && wg_kernarg()->fold_levels == 0) p.ws[(size_t)p.splits * p.blocks * (128 * 9 * 64) + ((size_t)split * p.blocks + block) * 128 + tid] = v;
-            else if (n0 + tid < p.N) atomicAdd(p.dbias + n0 + tid, v);
-        }
-    }
-
     // ---- flush: D[i = n][j = c] per tap; lane holds rows 4g..4g+3 (n), column il (c)
     if constexpr (S2) {                          // tap (jy, jx) of class (py, px) is weight tap (2 jy + 1 - py, 2 jx + 1 - px) of the 4x4 kernel
 #pragma unroll
@@ -912,37 +807,50 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
                     atomicAdd(row + (ky * 4 + kx) * C, acc[it][t][r]);
                 }
             }
-    } else {
-        int surv = split, nleft = p.splits;
-        const int fold_levels = wg_kernarg()->fold_levels;
-        if (p.splits > 1 && fold_levels > 0) {
-            WgKernargP kq = wg_kernarg();
-            surv = wgrad_tree_fold<4, NTAP>(acc, p.ws + (size_t)p.splits * p.blocks * (128 * 9 * 64), (int*)((char*)p.ws + kq->counters_off), smem, block, split,
-                                            p.splits, fold_levels, kq->nodes_per_block, wave, lane, tid);
-            if (surv < 0) return;
-            for (int L = 0; L < fold_levels; ++L) nleft = (nleft + 1) >> 1;
-        }
-        if (nleft == 1) {                        // sole owner of its dw elements within the launch
+    } else if (p.splits == 1) {                  // sole owner of its dw elements within the launch
 #pragma unroll
-            for (int it = 0; it < 4; ++it)
+        for (int it = 0; it < 4; ++it)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = n0 + wn * 64 + it * 16 + 4 * g + r;
-                    if (n >= p.N) continue;
-                    float* row = p.dw + (size_t)n * p.ldw + c0 + wc * 16 + il;
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + it * 16 + 4 * g + r;
+                if (n >= p.N) continue;
+                float* row = p.dw + (size_t)n * p.ldw + c0 + wc * 16 + il;
 #pragma unroll
-                    for (int t = 0; t < 9; ++t)
-                        if (c0 + wc * 16 + il < C) row[t * C] += acc[it][t][r];
-                }
-        } else {                                 // register image as it stands: 1 KiB contiguous per wave-instruction
-#if DM_WGRAD_NOFLUSH                             // diagnostic build only (results garbage): what the 288-KiB store tail of a workgroup costs
-            if (p.N > 0) return;
+                for (int t = 0; t < 9; ++t)
+                    if (c0 + wc * 16 + il < C) row[t * C] += acc[it][t][r];
+            }
+    } else {                                     // register image as it stands: 1 KiB contiguous per wave-instruction
+        // r04, two measurements behind keeping this two-launch form (profiles/r04_ab_same_box.txt):
+        //  * what the fold costs: with these stores compiled out (DM_WGRAD_NOFLUSH) dm_conv_wgrad takes 72 - 74 us instead of 82 - 84 on
+        //    the 64x64 / 32x32 / 16x16 layers — a ~10-us store tail (all 256 workgroups write their 288 KiB at once) + a ~17-us reduce launch;
+        //  * an in-kernel pairwise tree fold instead of the reduce launch (commit d33a092: of the two workgroups of a tree node the first
+        //    to arrive parks its image with sc1 stores and raises a ready word, the second polls it, loads the image with sc1 loads, adds
+        //    and moves up; no co-residency needed, fixed tree = fixed sums; bit-exact on every test): a level costs ~20 us — the store
+        //    drain of one workgroup followed by the dependent load batches of another, across XCDs, is a latency chain where the reduce
+        //    launch is a bandwidth-bound sweep by 9000 workgroups: 8x8 layers (2 splits, 1 level) 86 -> 108 us, 16x16 (8 splits, 3 levels)
+        //    81 -> 142 us, two / three levels ahead of a smaller reduce launch on the 32x32 / 64x64 layers 81 -> 96 / 105 us.  Every partial
+        //    has to leave its CU once whatever the scheme (256 x 288 KiB per launch), so a fold can only ever save the second pass.
+#if DM_WGRAD_NOFLUSH                             // diagnostic build only (results garbage)
+        if (p.N > 0) return;
 #endif
-            f32x4* dst = (f32x4*)p.ws + ((((size_t)surv * p.blocks + block) * 8 + wave) * 36) * 64 + lane;
+        f32x4* dst = (f32x4*)p.ws + ((((size_t)split * p.blocks + block) * 8 + wave) * 36) * 64 + lane;
 #pragma unroll
-            for (int it = 0; it < 4; ++it)
+        for (int it = 0; it < 4; ++it)
 #pragma unroll
-                for (int t = 0; t < NTAP; ++t) dst[(it * 9 + t) * 64] = acc[it][t];
+            for (int t = 0; t < NTAP; ++t) dst[(it * 9 + t) * 64] = acc[it][t];
+    }
+    if (want_bias) {                             // fold the 16 row groups in LDS, then one value per column and workgroup
+        __syncthreads();
+        float* sb = (float*)smem;                // [16][128]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sb[brow * 128 + bcol + e] = bsum[e];
+        __syncthreads();
+        if (tid < 128) {
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v += sb[j * 128 + tid];
+            if (p.splits > 1 && !S2) p.ws[(size_t)p.splits * p.blocks * (128 * 9 * 64) + ((size_t)split * p.blocks + block) * 128 + tid] = v;
+            else if (n0 + tid < p.N) atomicAdd(p.dbias + n0 + tid, v);
         }
     }
 }
@@ -1279,20 +1187,17 @@ int launch_wgrad_halo(const WgHP& p, hipStream_t st) {
     }
     hipLaunchKernelGGL((wgrad3x3_halo_kernel<T, TW>), dim3((unsigned)(p.blocks * p.splits)), dim3(512), bytes, st, p);
     DM_LAUNCH_CHECK();
-    int left = p.splits;                         // partials per block still in the workspace after the in-kernel fold levels
-    for (int L = 0; L < p.fold_levels; ++L) left = (left + 1) >> 1;
-    float* dbias = p.fold_levels > 0 ? nullptr : p.dbias;      // (a folding launch adds its bias sums with atomics)
-    if (left > 1) {
+    if (p.splits > 1) {
         const int per_split = p.blocks * 8 * 36 * 64;
-        if (left >= 32)
-            hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((unsigned)(per_split / 32 + cdiv(p.N, 4))), dim3(256), 0, st, (const f32x4*)p.ws, p.dw, dbias,
-                               p.N, p.C1 + p.C2, p.nchunks, p.blocks, p.ldw, left);
-        else if (left >= 8)
-            hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)(per_split / 64 + cdiv(p.N, 4))), dim3(256), 0, st, (const f32x4*)p.ws, p.dw, dbias,
-                               p.N, p.C1 + p.C2, p.nchunks, p.blocks, p.ldw, left);
+        if (p.splits >= 32)
+            hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((unsigned)(per_split / 32 + cdiv(p.N, 4))), dim3(256), 0, st, (const f32x4*)p.ws, p.dw, p.dbias,
+                               p.N, p.C1 + p.C2, p.nchunks, p.blocks, p.ldw, p.splits);
+        else if (p.splits >= 8)
+            hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)(per_split / 64 + cdiv(p.N, 4))), dim3(256), 0, st, (const f32x4*)p.ws, p.dw, p.dbias,
+                               p.N, p.C1 + p.C2, p.nchunks, p.blocks, p.ldw, p.splits);
         else
-            hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)(per_split / 256 + cdiv(p.N, 4))), dim3(256), 0, st, (const f32x4*)p.ws, p.dw, dbias,
-                               p.N, p.C1 + p.C2, p.nchunks, p.blocks, p.ldw, left);
+            hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)(per_split / 256 + cdiv(p.N, 4))), dim3(256), 0, st, (const f32x4*)p.ws, p.dw, p.dbias,
+                               p.N, p.C1 + p.C2, p.nchunks, p.blocks, p.ldw, p.splits);
         DM_LAUNCH_CHECK();
     }
     return DM_OK;
@@ -1314,9 +1219,6 @@ int launch_wgrad_tap4(const WgHP& p, hipStream_t st) {
 
 // the 4x4 / stride-2 / pad-1 layer (new_scripy.py:229) on output rows of 32 / 16 pixels or 8x8 output images, one source, whole
 // 64-channel chunks: the halo-resident kernel in its S2 form (one input-parity class per workgroup, atomics into dw)
-int g_wgrad_fold = 1;              // in-kernel pairwise fold of the halo weight gradient's pixel splits (dm_set_wgrad_fold)
-int g_wgrad_fold_max = 8;          // blocks with at most this many splits fold completely inside the launch
-int g_wgrad_fold_partial = 0;      // levels folded in-kernel ahead of the reduce launch when a block has more splits
 int g_wgrad_tap4 = 1;
 int g_wgrad_tap4_blocks = 256;     // workgroups the pixel split aims at (each adds 32768 floats to dw through atomics)
 bool wgrad_tap4_plan(const DmWgrad* d, int64_t M, WgHP& hp) {
@@ -1341,7 +1243,6 @@ bool wgrad_tap4_plan(const DmWgrad* d, int64_t M, WgHP& hp) {
     if (splits > hp.ntiles) splits = hp.ntiles;
     hp.tiles_per_split = cdiv(hp.ntiles, splits);
     hp.splits = cdiv(hp.ntiles, hp.tiles_per_split);
-    hp.fold_levels = 0; hp.nodes_per_block = 0; hp.counters_off = 0;
     return true;
 }
 
@@ -1375,19 +1276,6 @@ bool wgrad_halo_plan(const DmWgrad* d, int64_t M, WgHP& hp) {
     hp.tiles_per_split = cdiv(hp.ntiles, splits);
     hp.splits = cdiv(hp.ntiles, hp.tiles_per_split);
     if (hp.splits > 1 && (dm_g_ws == nullptr || (int64_t)hp.splits * hp.blocks * (128 * 9 * 64 * 4 + 128 * 4) > dm_g_ws_bytes)) return false;
-    // in-kernel pairwise fold (wgrad_tree_fold): all levels when a block has few splits (the deep layers: 2 .. g_wgrad_fold_max splits,
-    // the reduce launch disappears), else the first g_wgrad_fold_partial levels (0: none) ahead of a smaller reduce launch
-    hp.fold_levels = 0; hp.nodes_per_block = 0; hp.counters_off = dm_g_counters ? (long long)((char*)dm_g_counters - (char*)dm_g_ws) : 0;
-    if (hp.splits > 1 && dm_g_counters != nullptr && g_wgrad_fold) {
-        int all = 0;
-        for (int n = hp.splits; n > 1; n = (n + 1) >> 1) ++all;
-        int levels = hp.splits <= g_wgrad_fold_max ? all : (g_wgrad_fold_partial < all ? g_wgrad_fold_partial : all);
-        if (levels > 3) levels = 3;                                  // WG_FOLD_MAX_LEVELS of the kernel (8 splits fold completely)
-        int nodes = 0, n = hp.splits;
-        for (int L = 0; L < levels; ++L) { nodes += n >> 1; n = (n + 1) >> 1; }
-        const int64_t need = (int64_t)hp.splits * hp.blocks * (128 * 9 * 64 * 4) + (int64_t)hp.blocks * nodes * (128 * 9 * 64 * 4);
-        if (levels > 0 && hp.blocks * nodes <= 4096 && need <= dm_g_ws_bytes) { hp.fold_levels = levels; hp.nodes_per_block = nodes; }
-    }
     return true;
 }
 
@@ -1492,13 +1380,6 @@ int launch_wgrad_pw(const WgPwP& q, int ntw, int ctw, hipStream_t st) {
 static int g_last_wgrad_path = 0;   // 1: the last dm_conv_wgrad launch went to wgrad3x3_halo_kernel, 2: to wgrad_pw_kernel, 3: to the four-tap (S2) form of 1
 extern "C" int dm_last_wgrad_path(void) { return g_last_wgrad_path; }
 extern "C" int dm_set_wgrad_skinny(int on) { g_wgrad_skinny = on ? 1 : 0; return DM_OK; }
-extern "C" int dm_set_wgrad_fold(int on, int max_splits, int partial_levels) {
-    DM_CHECK_ARG(max_splits >= 0 && max_splits <= 8 && partial_levels >= 0 && partial_levels <= 3, "dm_set_wgrad_fold: max_splits 0 .. 8, partial_levels 0 .. 3 (the kernel folds at most three levels)");
-    g_wgrad_fold = on ? 1 : 0;
-    if (max_splits > 0) g_wgrad_fold_max = max_splits;
-    g_wgrad_fold_partial = partial_levels;
-    return DM_OK;
-}
 
 extern "C" int dm_set_wgrad_tap4(int on) {      // on > 1 also sets the workgroup target
     g_wgrad_tap4 = on != 0;

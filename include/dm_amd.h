@@ -111,11 +111,6 @@ int dm_last_wgrad_path(void);   /* 4: wgrad3x3_skinny_kernel (below) */
 /* on != 0 (default): the weight gradient of the full-resolution 3x3 layers with 8 (padded) channels on one side — the stem (new_scripy.py:381
    -> :184) and the head (:314) — on wgrad3x3_skinny_kernel (taps x 8 channels packed into the MFMA's column operand); 0: halo kernel */
 int dm_set_wgrad_skinny(int on);
-/* r04: in-kernel pairwise fold of the pixel splits of the 3x3 halo weight gradient (wgrad.hip, wgrad_tree_fold).  on = 0: every launch
- * parks all partials for the reduce launch (r03); max_splits (> 0): blocks with at most that many splits fold completely inside the
- * launch (default 8: the 16x16 / 8x8 layers lose their reduce launch); partial_levels: tree levels folded in-kernel ahead of a smaller
- * reduce launch on blocks with more splits (default 0).  Same sums in a fixed tree order either way.  DM_WGRAD_FOLD = "on[,max[,partial]]". */
-int dm_set_wgrad_fold(int on, int max_splits, int partial_levels);
 /* on != 0 (default): the weight gradient of the 16-bit 4x4 / stride-2 / pad-1 layers (output rows of 32 / 16 pixels or 8x8 output
    images) on the four-tap form of the halo-resident kernel; 0: per-tap kernel; > 1: also the workgroup count its pixel split aims at
    (default 256).  dm_last_wgrad_path() reports 3.  Measurement knob. */
