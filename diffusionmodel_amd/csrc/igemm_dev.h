@@ -85,7 +85,9 @@ __device__ __forceinline__ bool splitk_last_arriver(const ConvP& p, f32x4 (&acc)
     if (tid == 0) {
         const int old = __hip_atomic_fetch_add(p.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = old == p.splits - 1;
-        if (last) p.counters[tile_id] = 0;             // everyone has arrived: ready for the next launch on this stream
+        // everyone has arrived: ready for the next launch on this stream (an agent-scope atomic store, like the adds that will meet it:
+        // a plain store would sit in this XCD's L2 until the launch boundary's write-back — sufficient today, not by contract)
+        if (last) __hip_atomic_store(p.counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *flag = last;
     }
     __syncthreads();

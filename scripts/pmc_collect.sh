@@ -4,7 +4,7 @@
 set -e
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-CMD="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --sample-steps 0"
+CMD="python3 bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --sample-steps 0 --no-calibration --no-dp-probe"
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
   name=${pass%%:*}; ctr=${pass#*:}
   rm -rf gpurun_out/pmc_tmp

@@ -1169,3 +1169,34 @@ def test_lds_residue_audit_exact_integer_kernels_with_every_cu_lds_poisoned():
         L.POISON_LDS[0] = None
         lib.dm_set_conv_variant(L.DEFAULT_CONV_VARIANT)
     assert L.POISON_CALLS[0] > 500, L.POISON_CALLS[0]          # the poison launches really ran
+
+
+def test_coordattn_chain_respects_the_64_kib_rule_on_a_shared_gpu():
+    """when the device guard has switched the library to its <= 64-KiB-LDS kernels (conv variant 2: a GPU shared between
+    processes), the fused CoordAttn chain must not launch workgroups above 64 KiB either.  Strips of 128 + 128 positions x 16 channels need
+    61.9 KiB of dynamic LDS (+ 22 KiB static): the C ABI refuses them (DM_EUNSUPPORTED), ops.ca_chain_ok routes the block to the
+    one-launch-per-op path, and that path's result equals the chain's (fp32)."""
+    import diffusionmodel_amd as D
+    from diffusionmodel_amd import _lib as L, ops as o
+    lib = L.load()
+    torch.manual_seed(3)
+    ca = D.CoordAttn(256).to(DEV).eval()
+    with torch.no_grad():
+        for p_ in ca.parameters():
+            p_.normal_(0, 0.2)
+    x = torch.randn(2, 256, 128, 128, device=DEV)
+    assert o.ca_chain_lds(128, 128, 16) + 22 * 1024 > 64 * 1024
+    try:
+        with torch.no_grad():
+            assert o.ca_chain_ok(256, 16, 128, 128)
+            y_chain = ca(x)
+            assert lib.dm_set_conv_variant(2) == 0
+            assert not o.ca_chain_ok(256, 16, 128, 128) and o.ca_chain_ok(256, 16, 32, 32)
+            y_small = ca(x)                                   # per-op path (H == W)
+            d = L.DmCaChain()
+            d.B, d.H, d.W, d.C, d.R = 2, 128, 128, 256, 16
+            import ctypes as C
+            assert lib.dm_ca_chain_fwd(C.byref(d), None) == -2 and b"64-KiB" in lib.dm_last_error()
+    finally:
+        lib.dm_set_conv_variant(L.DEFAULT_CONV_VARIANT)
+    assert rel_err(y_small.cpu(), y_chain.cpu()) < 2e-4
