@@ -639,7 +639,7 @@ def main():
     # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes over this same
     # command (they cannot be collected from inside the process); the committed summary is quoted when present
     traffic, traffic_src = None, None
-    for cand in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
+    for cand in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", cand)) as f:
                 pmc = json.load(f)["kernels"].get("conv3x3_halo<bf16>" if dtype == torch.bfloat16 else "", None)
