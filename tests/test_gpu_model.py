@@ -764,6 +764,11 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     assert out["config"]["global_batch"] == 32 and out["config"]["exec"] == "plan" and out["config"]["backend"] == "gloo"
     assert out["value"] > 0 and out["loss"] == out["loss"] and out["sample"]["n"] == 32 and "error" not in out["sample"]
     assert "ranks share 1 device" in r.stderr
+    # r04: what the N > 1 line is read against — the data-parallel facts, the calibration block and the repeated regions
+    dp = out["dp"]
+    assert dp["ranks"] == 2 and dp["buckets"] >= 1 and dp["allreduce_bytes_per_step_per_rank"] > 4 * 1e6 and dp["tail_wait_ms"] >= 0.0
+    assert out["repeats"]["n"] == 5 and len(out["repeats"]["ms_per_step_all"]) == 5
+    assert out["calibration"]["conv_random_us"] > 0 and out["calibration"]["copy_1GiB_TBps"] > 0
 
 
 def test_replay_after_an_eager_backward_without_a_step_starts_from_clean_accumulators():
