@@ -272,7 +272,26 @@ def calibration(dev, iters=300):
         us = e0.elapsed_time(e1) * 1e3 / iters
         out["conv_%s_us" % tag] = round(us, 2)
         out["conv_%s_tflops" % tag] = round(flops / (us * 1e-6) / 1e12, 1)
-    del x, w, y
+    # (4) the same convolution ALTERNATING with the BatchNorm + GELU pass over its output (MFMA-bound / HBM-bound, as in the step): the
+    # clock a box holds under the step's mixed load differs more between boxes than under either kernel alone
+    x = torch.randn(B, H, H, Ci, device=dev, generator=g).bfloat16()
+    w = (torch.randn(Co, k, k, Ci, device=dev, generator=g) / (Ci * k * k) ** 0.5).bfloat16()
+    a = torch.empty_like(y)
+    mean, rstd, gamma, beta = torch.zeros(Co, device=dev), torch.ones(Co, device=dev), torch.ones(Co, device=dev), torch.zeros(Co, device=dev)
+
+    def pair():
+        ops._conv_call(x, None, w.data_ptr(), k * k * Ci, y, **geom)
+        ops.call("dm_bn_act_fwd", ops.ptr(y), ops.ptr(a), ops.L.DM_BF16, B * H * H, Co, ops.ptr(mean), ops.ptr(rstd), ops.ptr(gamma), ops.ptr(beta), ops.L.ACT_GELU)
+    for _ in range(10):
+        pair()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters // 2):
+        pair()
+    e1.record()
+    torch.cuda.synchronize()
+    out["mixed_conv_bn_us"] = round(e0.elapsed_time(e1) * 1e3 / (iters // 2), 2)
+    del x, w, y, a
     n = 1 << 28
     a, b = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
     a.fill_(1.0)

@@ -122,7 +122,7 @@ _PROTOS = {
     "dm_plan_run_timed": [vp, i32, i32, C.c_char_p],
     "dm_plan_timed_results": [vp, vp, vp, i32, vp],
 }
-_NO_STREAM = {"dm_last_conv_path": ([], i32), "dm_last_wgrad_path": ([], i32), "dm_get_conv_variant": ([], i32), "dm_set_conv_tap4": ([i32], i32), "dm_set_conv_persist": ([i32], i32), "dm_set_conv_packtap": ([i32], i32), "dm_last_conv_persistent": ([], i32), "dm_set_wgrad_pw": ([i32, i32, i32], i32), "dm_set_wgrad_tap4": ([i32], i32), "dm_set_wgrad_skinny": ([i32], i32), "dm_set_splitk_inkernel": ([i32], i32), "dm_set_workspace": ([vp, i64], i32), "dm_set_conv_variant": ([i32], i32), "dm_set_wgrad_variant": ([i32], i32), "dm_version": ([], i32), "dm_last_error": ([], C.c_char_p), "dm_colstat_blocks": ([i32], i32),
+_NO_STREAM = {"dm_last_conv_path": ([], i32), "dm_last_wgrad_path": ([], i32), "dm_get_conv_variant": ([], i32), "dm_set_conv_tap4": ([i32], i32), "dm_set_conv_persist": ([i32], i32), "dm_set_conv_packtap": ([i32], i32), "dm_last_conv_persistent": ([], i32), "dm_set_wgrad_pw": ([i32, i32, i32], i32), "dm_set_wgrad_tap4": ([i32], i32), "dm_set_wgrad_skinny": ([i32], i32), "dm_set_conv_wave4": ([i32], i32), "dm_set_splitk_inkernel": ([i32], i32), "dm_set_workspace": ([vp, i64], i32), "dm_set_conv_variant": ([i32], i32), "dm_set_wgrad_variant": ([i32], i32), "dm_version": ([], i32), "dm_last_error": ([], C.c_char_p), "dm_colstat_blocks": ([i32], i32),
               "dm_plan_from_graph": ([vp, C.POINTER(vp)], i32), "dm_plan_info": ([vp, C.POINTER(i32)], i32),
               "dm_plan_segment_marker": ([vp, i32], i32), "dm_plan_op_name": ([vp, i32, C.c_char_p, i32], i32),
               "dm_plan_destroy": ([vp], i32),
@@ -171,6 +171,9 @@ def load():
     v = os.environ.get("DM_WGRAD_SKINNY")      # 0: the stem / head weight gradients stay on the halo kernel (A/B measurements)
     if v is not None:
         lib.dm_set_wgrad_skinny(int(v))
+    v = os.environ.get("DM_CONV_WAVE4")        # 1 / 2: the four-wave form of the 3x3 halo kernel (r04 experiment, igemm_halo4.hip)
+    if v is not None and lib.dm_set_conv_wave4(int(v)) != 0:
+        raise DmError(lib.dm_last_error().decode())
     v = os.environ.get("DM_WGRAD_TAP4")        # 0: the 4x4 / stride-2 weight gradients stay on the per-tap kernel
     if v is not None:
         lib.dm_set_wgrad_tap4(int(v))

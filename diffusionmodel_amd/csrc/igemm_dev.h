@@ -299,7 +299,9 @@ __device__ __forceinline__ void conv_store(const ConvP& p, f32x4 (&acc)[BN / 32]
     }
 }
 
-template <typename T, int BN>
+// PHASE: bit 0 = this call's column sums go to the LDS fold, bit 1 = barrier + publish the fold (both `wm` slots).  3 = the whole
+// epilogue in one call (every kernel but the four-wave halo form, whose waves hold two `wm` rows and call it once per row: 1, then 3)
+template <typename T, int BN, int PHASE = 3>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 32][4], char* smem, int tid, int wm, int wn, int fr,
                                               int fg, int mb, int m0, int n0) {
     constexpr int NT = BN / 32;
@@ -379,7 +381,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[BN / 
     else if (p.act == DM_ACT_GELU) conv_store<T, BN, DM_ACT_GELU>(p, acc, m_ok, orow, ob, oy, ox, wn, fg, n0);
     else conv_store<T, BN, -1>(p, acc, m_ok, orow, ob, oy, ox, wn, fg, n0);
 
-    if (p.psum) {                                          // after the stores: the barrier's wait for the slowest wave hides behind them
+    if (p.psum && (PHASE & 2)) {                           // after the stores: the barrier's wait for the slowest wave hides behind them
         const float* sred = (const float*)smem;
         __syncthreads();
         if (tid < BN && n0 + tid < p.N) {
@@ -410,6 +412,8 @@ constexpr int SRD_FLAGS = 0x00020000;
 extern int g_splitk_inkernel;        // igemm.hip
 extern int g_last_path;              // igemm.hip: kernel family of the last dm_conv launch
 int launch_halo_any(const ConvP& p, bool is_f16, hipStream_t st);                          // igemm_halo.hip
+bool halo4_ok(const ConvP& p);                                                             // igemm_halo4.hip (r04 experiment: one wave per SIMD)
+int launch_halo4_any(const ConvP& p, bool is_f16, hipStream_t st);
 extern int g_last_persist;
 extern int g_conv_persist;           // igemm.hip: 1 = persistent halo kernel where halo_persist_ok()
 bool halo_persist_ok(const ConvP& p, int tiles, int ncu);                                  // igemm_halo_p.hip

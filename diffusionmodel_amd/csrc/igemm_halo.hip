@@ -291,6 +291,7 @@ int launch_halo(const ConvP& p, hipStream_t st) {
             q.counters = g_splitk_inkernel ? dm_g_counters : nullptr;   // the last split to arrive runs the epilogue in the same launch
         }
     }
+    if (TW == 64 && halo4_ok(q)) return launch_halo4_any(q, std::is_same<T, f16>::value, st);      // (experiment, off by default)
     if (q.splits == 1 && g_conv_persist) {          // persistent workgroups with cross-tile prefetch (igemm_halo_p.hip) where they apply
         static int ncu = 0;
         if (ncu == 0) {

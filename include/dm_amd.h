@@ -111,6 +111,10 @@ int dm_last_wgrad_path(void);   /* 4: wgrad3x3_skinny_kernel (below) */
 /* on != 0 (default): the weight gradient of the full-resolution 3x3 layers with 8 (padded) channels on one side — the stem (new_scripy.py:381
    -> :184) and the head (:314) — on wgrad3x3_skinny_kernel (taps x 8 channels packed into the MFMA's column operand); 0: halo kernel */
 int dm_set_wgrad_skinny(int on);
+/* r04 experiment (igemm_halo4.hip): the 3x3 halo kernel with one wave per SIMD (four waves, 128 x 64 wave tiles) on rows of >= 64
+ * pixels, one source.  0 = off (default), 1 = compiler schedule, 2 = fragments prefetched one sub-step ahead on a pinned schedule.
+ * Bit-identical results either way; measured 2 - 4 % slower than the eight-wave kernel.  DM_CONV_WAVE4. */
+int dm_set_conv_wave4(int mode);
 /* on != 0 (default): the weight gradient of the 16-bit 4x4 / stride-2 / pad-1 layers (output rows of 32 / 16 pixels or 8x8 output
    images) on the four-tap form of the halo-resident kernel; 0: per-tap kernel; > 1: also the workgroup count its pixel split aims at
    (default 256).  dm_last_wgrad_path() reports 3.  Measurement knob. */

@@ -1200,3 +1200,52 @@ def test_coordattn_chain_respects_the_64_kib_rule_on_a_shared_gpu():
     finally:
         lib.dm_set_conv_variant(L.DEFAULT_CONV_VARIANT)
     assert rel_err(y_small.cpu(), y_chain.cpu()) < 2e-4
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("B,H,C,N,dtype", [(6, 64, 128, 128, torch.bfloat16), (3, 64, 64, 192, torch.float16), (2, 128, 64, 128, torch.bfloat16)])
+def test_four_wave_halo_kernel_is_bit_identical_to_the_eight_wave_kernel(B, H, C, N, dtype, mode):
+    """r04 experiment (igemm_halo4.hip, dm_set_conv_wave4): the 3x3 halo kernel with one wave per SIMD — four waves, 128 x 64 wave tiles,
+    the shared epilogue once per image row of a wave — keeps the tile, the LDS image and the order of the fp32 sums of the eight-wave
+    kernel: forward (plain and with BatchNorm statistics + GELU), input gradient with the forked-gradient addend, ragged N, 128-pixel
+    rows (column tiles) must agree BIT FOR BIT on random data (statistics to the fp64-atomics band)."""
+    o = ops()
+    from diffusionmodel_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(B + H + C + N)
+    x = torch.randn(B, H, H, C).to(dtype).to(DEV)
+    w = torch.nn.Parameter((torch.randn(N, C, 3, 3) / math.sqrt(9 * C)).to(DEV).contiguous(memory_format=torch.channels_last))
+    bias = torch.nn.Parameter(torch.randn(N).to(DEV) * 0.1)
+    probe = torch.randn(B, H, H, N).to(dtype).to(DEV)
+    bn = torch.nn.BatchNorm2d(N).to(DEV)
+    bn.train()
+    sd = {k: v.clone() for k, v in bn.state_dict().items()}
+
+    def run(wave4, with_bn):
+        lib.dm_set_conv_wave4(wave4)
+        bn.load_state_dict(sd)
+        xd = x.clone().requires_grad_(True)
+        w.grad = bias.grad = None
+        fork = o.GradFork()
+        conv = Holder.__new__(Holder)
+        conv.weight, conv.bias = w, bias
+        spec = o.ConvSpec(3, 3, 1, 1, o.ACT_GELU if with_bn else o.ACT_NONE, bn if with_bn else None)
+        y = o.conv_bn_act(xd, None, conv, bn if with_bn else None, spec, fork if C == N else None)
+        loss = (y.float() * probe.float()).sum()
+        if C == N:
+            loss = loss + ((fork.second(xd).float() + 0.0 * y.float()) * 0.5).sum()
+        loss.backward()
+        return [y.detach().clone(), xd.grad.clone(), bn.running_var.clone(), bn.running_mean.clone()]
+    try:
+        lib.dm_set_conv_persist(0)
+        for with_bn in (False, True):
+            a = run(mode, with_bn)
+            b_ = run(0, with_bn)
+            for name, u, v in zip(("y", "dx", "running_var", "running_mean"), a, b_):
+                if name in ("y", "dx") and not with_bn:
+                    assert torch.equal(u, v), (with_bn, name, float((u.float() - v.float()).abs().max()))
+                else:
+                    assert torch.allclose(u.float(), v.float(), rtol=2e-3, atol=2e-3 * float(v.float().abs().max())), (with_bn, name)
+    finally:
+        lib.dm_set_conv_wave4(0)
+        lib.dm_set_conv_persist(1)
