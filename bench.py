@@ -272,6 +272,17 @@ def calibration(dev, iters=300):
         us = e0.elapsed_time(e1) * 1e3 / iters
         out["conv_%s_us" % tag] = round(us, 2)
         out["conv_%s_tflops" % tag] = round(flops / (us * 1e-6) / 1e12, 1)
+        if tag == "random":
+            # the same launch SUSTAINED: ~0.4 s more of it, then 1000 timed launches — the clock a box settles at under a long MFMA load
+            # (boxes whose 300-launch figures agree to 1 % run the step's MFMA kernels 5 % apart: r04)
+            for _ in range(5000):
+                ops._conv_call(x, None, w.data_ptr(), k * k * Ci, y, **geom)
+            e0.record()
+            for _ in range(1000):
+                ops._conv_call(x, None, w.data_ptr(), k * k * Ci, y, **geom)
+            e1.record()
+            torch.cuda.synchronize()
+            out["conv_random_sustained_us"] = round(e0.elapsed_time(e1), 2)        # ms per 1000 launches = us per launch
     # (4) the same convolution ALTERNATING with the BatchNorm + GELU pass over its output (MFMA-bound / HBM-bound, as in the step): the
     # clock a box holds under the step's mixed load differs more between boxes than under either kernel alone
     x = torch.randn(B, H, H, Ci, device=dev, generator=g).bfloat16()

@@ -67,17 +67,22 @@ __device__ __forceinline__ void store_partial(const ConvP& p, const f32x4 (&acc)
 // came last — told by the value the add returned — loads the partials with `sc1` loads behind a workgroup barrier that lane joins.
 // No fence, no L2 write-back.  (The workspace lines cannot sit stale in the reader's L2: nothing on that XCD reads them in this
 // launch before the hand-off, and a launch boundary invalidates what earlier launches left.)
-__device__ __forceinline__ void st_sc1(f32x4* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void ld_sc1(f32x4& v, const f32x4* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory"); }
+// r04: the partials travel as BUFFER stores / loads with the sc1 cache policy (aux = 16) — compiler-visible, so the
+// `s_waitcnt` in front of each use is the compiler's own, and no address registers (lane offset in one VGPR, image offset scalar).  r03 used
+// inline-asm `global_load/store … sc1`, whose memory operations the compiler's waitcnt tracking cannot see: correct only as long as no
+// copy or spill of a loaded register lands between the asm load and the hand-written wait.
+constexpr int SC1_POLICY = 16;
 
 __device__ __forceinline__ bool splitk_last_arriver(const ConvP& p, f32x4 (&acc)[4][4], char* smem, int split, int ntiles2, int tile_id,
                                                     int half_tile, int wave4, int tid, int lane) {
+    const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc((void*)p.ws, 0, 0x7fffffff, 0x00020000);
     {
-        f32x4* dst = (f32x4*)p.ws + ((((size_t)split * ntiles2 + half_tile) * 4 + wave4) * 16) * 64 + lane;
+        const int soff = (((split * ntiles2 + half_tile) * 4 + wave4) * 16) * 1024;       // bytes; the workspace is < 2^31
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) st_sc1(dst + (nt * 4 + mt) * 64, acc[nt][mt]);
+            for (int mt = 0; mt < 4; ++mt)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[nt][mt]), rws, lane * 16, soff + (nt * 4 + mt) * 1024, SC1_POLICY);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partials have left for memory
     __syncthreads();                                   // ... and every other wave's of this workgroup
@@ -99,20 +104,14 @@ __device__ __forceinline__ bool splitk_last_arriver(const ConvP& p, f32x4 (&acc)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < p.splits; ++k) {
-        const f32x4* src = (const f32x4*)p.ws + ((((size_t)k * ntiles2 + half_tile) * 4 + wave4) * 16) * 64 + lane;
-        f32x4 v[16];
+        const int soff = (((k * ntiles2 + half_tile) * 4 + wave4) * 16) * 1024;
+        u32x4 v[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) ld_sc1(v[i], src + i * 64);
-        // the loads are invisible to the compiler's counters: wait here, with the values as operands so that no use moves above it
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
-                       "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
-                     :
-                     : "memory");
+        for (int i = 0; i < 16; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane * 16, soff + i * 1024, SC1_POLICY);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[nt][mt] += v[nt * 4 + mt];
+            for (int mt = 0; mt < 4; ++mt) acc[nt][mt] += __builtin_bit_cast(f32x4, v[nt * 4 + mt]);
     }
     __syncthreads();                                   // the flag word is LDS the epilogue reuses
     return true;
