@@ -29,7 +29,7 @@ class DmConv(C.Structure):
 class DmWgrad(C.Structure):
     _fields_ = [(n, vp) for n in ("dy", "in1", "in2", "dw", "dbias")] + [
         (n, i32) for n in ("dtype", "B", "Hi", "Wi", "C1", "C2", "Hq", "Wq", "sy", "sx", "T", "KW", "ty", "tx", "oy0", "ox0",
-                           "Ho", "Wo", "osy", "osx", "ooy", "oox", "N", "ldy", "ldw", "splitk")]
+                           "Ho", "Wo", "osy", "osx", "ooy", "oox", "N", "ldy", "ldw", "splitk", "overwrite")]
 
 
 class DmCaChain(C.Structure):
@@ -98,6 +98,7 @@ _PROTOS = {
     "dm_add": [vp, vp, vp, i32, i64],
     "dm_mask_axpy": [vp, vp, vp, f32, vp, i32, i64, i32],
     "dm_scatter_copy": [vp, i32, i32],
+    "dm_zero_ranges": [vp, i32],
     "dm_image_moments": [vp, vp, vp, i32, i64],
     "dm_attn_mask": [vp, vp, i32, i32, f32, f32, f32],
     "dm_draw_ts_keep": [vp, vp, vp, i32, i32, f32, u64, vp],

@@ -399,6 +399,22 @@ extern "C" int dm_scatter_copy(const int64_t* table_dev, int n_entries, int add,
     return DM_OK;
 }
 
+namespace {
+__global__ void zero_ranges_kernel(const int64_t* table, int n_entries) {
+    for (int e = blockIdx.x; e < n_entries; e += gridDim.x) {
+        f32x4* dst = (f32x4*)table[2 * e + 0];
+        const int64_t n4 = table[2 * e + 1] >> 2;
+        for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+}  // namespace
+extern "C" int dm_zero_ranges(const int64_t* table_dev, int n_entries, dm_stream_t s) {
+    DM_CHECK_ARG(table_dev && n_entries > 0, "dm_zero_ranges: bad arguments");
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3(n_entries < 4096 ? n_entries : 4096), dim3(256), 0, ST, table_dev, n_entries);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
 // ---- evaluation helpers (new_scripy.py:1188-1250) and attention-mask rasterisation (:533-546) ------------------
 namespace {
 // one workgroup per image pair: {sum a, sum b, sum a^2, sum b^2, sum ab, min a, min b, n} in double

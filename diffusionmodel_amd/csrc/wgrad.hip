@@ -861,7 +861,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgHP p) {
 // a 16-deep chain of load batches on 144 workgroups — 18 us for 75 MB); the eight partial sums fold through LDS in a fixed order.
 template <int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restrict__ ws, float* __restrict__ dw, float* __restrict__ dbias, int N,
-                                                            int C, int nchunks, int blocks, int ldw, int splits) {
+                                                            int C, int nchunks, int blocks, int ldw, int splits, int overwrite) {
     constexpr int EPB = 256 / SL;                // elements per workgroup
     __shared__ f32x4 red[SL > 1 ? 256 : 1];
     const int per_split = blocks * 8 * 36 * 64;
@@ -899,7 +899,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restri
     float* o = dw + (size_t)n * ldw + t * C + chunk * 64 + (wave >> 1) * 16 + (lane & 15);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        if (n + r < N && chunk * 64 + (wave >> 1) * 16 + (lane & 15) < C) o[(size_t)r * ldw] += s[r];
+        if (n + r < N && chunk * 64 + (wave >> 1) * 16 + (lane & 15) < C) {
+            if (overwrite) o[(size_t)r * ldw] = s[r];           // DmWgrad.overwrite: dw was not zeroed (no read of it either)
+            else o[(size_t)r * ldw] += s[r];
+        }
 }
 
 // =================================================================================================
@@ -1177,7 +1180,11 @@ int launch_wgrad(WgP& p, int splitk_req, bool v2_ok, hipStream_t st) {
 }  // namespace
 
 template <typename T, int TW>
-int launch_wgrad_halo(const WgHP& p, hipStream_t st) {
+int launch_wgrad_halo(const WgHP& p, hipStream_t st, int overwrite) {
+    if (overwrite && p.splits == 1) {             // the kernel adds into dw itself: zero its rows first (rare: >= 256 output blocks)
+        hipError_t e = hipMemsetAsync(p.dw, 0, (size_t)p.N * p.ldw * sizeof(float), st);
+        if (e != hipSuccess) { dm_set_error("dm_conv_wgrad: hipMemsetAsync failed: %s", hipGetErrorString(e)); return (int)e; }
+    }
     constexpr int bytes = 2 * WGH_STAGE;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1191,13 +1198,13 @@ int launch_wgrad_halo(const WgHP& p, hipStream_t st) {
         const int per_split = p.blocks * 8 * 36 * 64;
         if (p.splits >= 32)
             hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((unsigned)(per_split / 32 + cdiv(p.N, 4))), dim3(256), 0, st, (const f32x4*)p.ws, p.dw, p.dbias,
-                               p.N, p.C1 + p.C2, p.nchunks, p.blocks, p.ldw, p.splits);
+                               p.N, p.C1 + p.C2, p.nchunks, p.blocks, p.ldw, p.splits, overwrite);
         else if (p.splits >= 8)
             hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)(per_split / 64 + cdiv(p.N, 4))), dim3(256), 0, st, (const f32x4*)p.ws, p.dw, p.dbias,
-                               p.N, p.C1 + p.C2, p.nchunks, p.blocks, p.ldw, p.splits);
+                               p.N, p.C1 + p.C2, p.nchunks, p.blocks, p.ldw, p.splits, overwrite);
         else
             hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)(per_split / 256 + cdiv(p.N, 4))), dim3(256), 0, st, (const f32x4*)p.ws, p.dw, p.dbias,
-                               p.N, p.C1 + p.C2, p.nchunks, p.blocks, p.ldw, p.splits);
+                               p.N, p.C1 + p.C2, p.nchunks, p.blocks, p.ldw, p.splits, overwrite);
         DM_LAUNCH_CHECK();
     }
     return DM_OK;
@@ -1420,10 +1427,18 @@ extern "C" int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream) {
     DM_CHECK_ARG((int64_t)d->T * cdiv(d->C1 + d->C2, 128) < 65536, "dm_conv_wgrad: grid.y too large");
     WgHP hp;
     g_last_wgrad_path = 0;
+    // DmWgrad.overwrite on a path that accumulates through atomics: zero dw here (the halo path below handles it in its reduce launch)
+    auto zero_dw = [&]() -> int {
+        if (!d->overwrite) return DM_OK;
+        hipError_t e = hipMemsetAsync(d->dw, 0, (size_t)d->N * d->ldw * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) { dm_set_error("dm_conv_wgrad: hipMemsetAsync failed: %s", hipGetErrorString(e)); return (int)e; }
+        return DM_OK;
+    };
     {
         WgSP sp;
         const int sk = wgrad_skinny_plan(d, M, sp);         // 1: stem form, 2: head form
         if (sk != 0) {
+            if (int rc = zero_dw()) return rc;
             g_last_wgrad_path = 4;
             return launch_wgrad_skinny(sp, sk == 2, d->dtype == DM_F16, (hipStream_t)stream);
         }
@@ -1432,16 +1447,17 @@ extern "C" int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream) {
         g_last_wgrad_path = 1;
         hipStream_t hst = (hipStream_t)stream;
         if (d->dtype == DM_F16) {
-            if (d->Wi >= 64) return launch_wgrad_halo<f16, 64>(hp, hst);
-            if (d->Wi == 32) return launch_wgrad_halo<f16, 32>(hp, hst);
-            if (d->Wi == 16) return launch_wgrad_halo<f16, 16>(hp, hst);
-            return launch_wgrad_halo<f16, 8>(hp, hst);
+            if (d->Wi >= 64) return launch_wgrad_halo<f16, 64>(hp, hst, d->overwrite);
+            if (d->Wi == 32) return launch_wgrad_halo<f16, 32>(hp, hst, d->overwrite);
+            if (d->Wi == 16) return launch_wgrad_halo<f16, 16>(hp, hst, d->overwrite);
+            return launch_wgrad_halo<f16, 8>(hp, hst, d->overwrite);
         }
-        if (d->Wi >= 64) return launch_wgrad_halo<bf16, 64>(hp, hst);
-        if (d->Wi == 32) return launch_wgrad_halo<bf16, 32>(hp, hst);
-        if (d->Wi == 16) return launch_wgrad_halo<bf16, 16>(hp, hst);
-        return launch_wgrad_halo<bf16, 8>(hp, hst);
+        if (d->Wi >= 64) return launch_wgrad_halo<bf16, 64>(hp, hst, d->overwrite);
+        if (d->Wi == 32) return launch_wgrad_halo<bf16, 32>(hp, hst, d->overwrite);
+        if (d->Wi == 16) return launch_wgrad_halo<bf16, 16>(hp, hst, d->overwrite);
+        return launch_wgrad_halo<bf16, 8>(hp, hst, d->overwrite);
     }
+    if (int rc = zero_dw()) return rc;
     if (wgrad_tap4_plan(d, M, hp)) {
         g_last_wgrad_path = 3;
         hipStream_t hst = (hipStream_t)stream;

@@ -348,7 +348,7 @@ def _conv_parity4_call(calls):
 
 
 def _wgrad_call(dy, in1, in2, dw, dbias, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0, Ho, Wo, N, ldy,
-                ldw, osy=1, osx=1, ooy=0, oox=0, splitk=0):
+                ldw, osy=1, osx=1, ooy=0, oox=0, splitk=0, overwrite=False):
     L.ensure_workspace()          # split partial sums of the halo-resident weight-gradient kernel
     key = ("w", dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy, sx, T, KW, ty, tx, oy0, ox0, Ho, Wo, N, ldy, ldw, osy, osx, ooy, oox, splitk)
     cache = _desc_cache()
@@ -363,6 +363,7 @@ def _wgrad_call(dy, in1, in2, dw, dbias, *, dtype, B, Hi, Wi, C1, C2, Hq, Wq, sy
         d.N, d.ldy, d.ldw, d.splitk = N, ldy, ldw, splitk
         cache[key] = d
     d.dy, d.in1, d.in2, d.dw, d.dbias = ptr(dy), ptr(in1), ptr(in2), ptr(dw), ptr(dbias)
+    d.overwrite = 1 if overwrite else 0          # dw holds garbage (FusedAdamW's lazy zero_grad): the launch leaves dw = this gradient
     kind = "conv_wgrad" if dtype != torch.float32 else "wgrad_f32"
     if PROFILE_META is not None:
         call("dm_conv_wgrad", C.byref(d))
@@ -629,7 +630,13 @@ class ConvBnAct(torch.autograd.Function):
                     tgt = main
                 else:
                     tgt = _zeros((N, kh, kw, Cin), torch.float32, g)
-                _wgrad_call(dz, x, x2, tgt, db, **wg_geom)
+                # FusedAdamW.zero_grad leaves the gradient ranges of the layers on the halo weight-gradient kernel un-zeroed and marks
+                # them fresh: the first launch into such a range overwrites (its reduce launch writes instead of read-modify-writing)
+                fresh = main is not None and getattr(w, "_dm_fresh", False)
+                _wgrad_call(dz, x, x2, tgt, db, overwrite=fresh, **wg_geom)
+                if main is not None:
+                    w._dm_fresh = False
+                    w._dm_halo_ok = getattr(w, "_dm_halo_ok", True) and L.load().dm_last_wgrad_path() == 1
                 dw = None if main is not None else tgt.permute(0, 3, 1, 2)
                 if main is not None and ON_WGRAD is not None:
                     ON_WGRAD(w)

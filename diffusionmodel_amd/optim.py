@@ -6,6 +6,7 @@ accumulate straight into it (`param.main_grad`), the few hundred small parameter
 are gathered by ONE multi-tensor launch, and one sum-of-squares + one AdamW launch finish the step.
 The flat gradient buffer is also what the data-parallel all-reduce works on (parallel.py).
 """
+import os
 import weakref
 
 import torch
@@ -66,6 +67,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self._hyper_host = None                       # last values uploaded: re-sent only when a hyper-parameter changes
         self._table = None                            # (pinned host, device) pointer table of gather_grads
         self._step_dev = torch.zeros(1, dtype=torch.int64, device=dev)   # step count on the device (bias corrections)
+        self._lazy = None                             # (table, rows, parameters) of the lazy zero_grad, learned from the first step
+        self._lazy_enabled = os.environ.get("DM_LAZY_ZERO", "1") != "0"
         self._captured_tables = []                    # pointer tables a stream capture baked into a graph: never reused
         self._capture_spare = None                    # the table the next capture will take (allocated on the eager path)
         self.refresh_shadow()
@@ -87,9 +90,54 @@ class FusedAdamW(torch.optim.Optimizer):
 
     # ------------------------------------------------------------------------------------------
     def zero_grad(self, set_to_none=True):
-        self.flat_g.zero_()
+        """r04: the ranges of the parameters whose weight gradient comes from the halo kernel + its reduce launch (the 3x3 layers: ~3/4 of
+        the buffer) are NOT zeroed — they are marked fresh and their first weight-gradient launch overwrites (DmWgrad.overwrite: the
+        reduce launch writes instead of read-modify-writing): the 426-MB fill becomes one dm_zero_ranges launch over the rest.  Which
+        parameters those are is learned from the first complete step (ops sets `_dm_halo_ok`); until then, and with DM_LAZY_ZERO=0, the
+        whole buffer is filled.  A fresh parameter that no launch wrote is zeroed by settle_fresh() before anything reads the buffer."""
+        if self._lazy is None:
+            self.flat_g.zero_()
+        else:
+            table, n_rows, lazy = self._lazy
+            if n_rows:
+                call("dm_zero_ranges", ptr(table), n_rows)
+            for p in lazy:
+                p._dm_fresh = True
         for p, _, _ in self._slots:
             p.grad = None
+
+    def settle_fresh(self):
+        """Zero the gradient range of every lazily-zeroed parameter that no weight-gradient launch has written since zero_grad()
+        (an unused layer, a rank without a micro-batch): called before anything reads the flat buffer — the all-reduce, the norm, AdamW."""
+        if self._lazy is None:
+            return
+        for p in self._lazy[2]:
+            if getattr(p, "_dm_fresh", False):
+                p.main_grad.zero_()
+                p._dm_fresh = False
+
+    def _learn_lazy(self):
+        """After the first complete step: the parameters every weight-gradient launch of which took the halo kernel -> the lazy set; the
+        complement of their ranges -> the table dm_zero_ranges walks (chunks of <= 256 Ki floats, one workgroup each)."""
+        lazy = [p for p, _, _ in self._slots if hasattr(p, "main_grad") and getattr(p, "_dm_halo_ok", False)]
+        ids = {id(p) for p in lazy}
+        rows, base, lo = [], self.flat_g.data_ptr(), None
+        spans, cur = [], None
+        for p, off, n in self._slots:
+            n4 = (n + 3) // 4 * 4
+            if id(p) in ids:
+                if cur is not None:
+                    spans.append(cur)
+                    cur = None
+            else:
+                cur = [off, off + n4] if cur is None else [cur[0], off + n4]
+        if cur is not None:
+            spans.append(cur)
+        for a, b in spans:
+            for x in range(a, b, 1 << 18):
+                rows.append((base + 4 * x, min(1 << 18, b - x)))
+        table = torch.tensor(rows if rows else [(0, 0)], dtype=torch.int64).to(self.flat_g.device)
+        self._lazy = (table, len(rows), lazy)
 
     def _new_table(self, cap):
         return [torch.empty((cap, 3), dtype=torch.int64).pin_memory(),
@@ -160,6 +208,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             raise DmError("FusedAdamW.step does not take a closure")
         ops.L.device_guard(recheck=True)             # one process per GPU, re-tested every step (two system calls)
+        self.settle_fresh()
         self.gather_grads()
         self._step += 1
         self.sync_hyper()
@@ -176,6 +225,8 @@ class FusedAdamW(torch.optim.Optimizer):
              ptr(self._sumsq), ptr(self._hyper), ptr(self.flat_p16), ops.dt(self.flat_p16), ptr(self._step_dev), ptr(state))
         ops.bump_weight_epoch()
         ops.refresh_packs()                          # every transposed (input-gradient) weight pack, one launch
+        if self._lazy is None and self._lazy_enabled and not torch.cuda.is_current_stream_capturing():
+            self._learn_lazy()
 
     def sync_hyper(self):
         """Upload lr / betas / eps / weight decay / clip norm when they differ from the device copy (lr schedules)."""

@@ -273,6 +273,9 @@ class OverlappedGradReducer:
         idle=True: this rank ran NO backward pass under the reducer for this step (short tail of an epoch: its peers did) — it
         issues the same collectives in the order an overlapped step issues them, contributing whatever its buffers hold."""
         self._ops.ON_WGRAD = None
+        settle = getattr(self.opt, "settle_fresh", None)
+        if settle is not None:
+            settle()                                  # lazily-zeroed gradient ranges nobody wrote (an idle rank: all of them) are zeros now
         if not self.active:
             return
         if idle:

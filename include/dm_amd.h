@@ -100,6 +100,9 @@ typedef struct DmWgrad {
     int32_t T, KW, ty, tx, oy0, ox0;
     int32_t Ho, Wo, osy, osx, ooy, oox;
     int32_t N, ldy, ldw, splitk;
+    int32_t overwrite;            /* r04: != 0 -> dw holds garbage: the launch leaves dw = this gradient (dbias still accumulates).  The 3x3 halo
+                                     kernel's reduce launch then writes instead of read-modify-writing, so the caller need not have zeroed dw
+                                     (FusedAdamW.zero_grad leaves those ranges alone); every other kernel path zeroes dw itself first. */
 } DmWgrad;
 int dm_conv_wgrad(const DmWgrad* d, dm_stream_t stream);
 /* tuning knob: 1 = register staging, 2 = LDS-DMA, 3 (default) = 2 + the halo-resident kernel for 3x3 stride-1 layers
@@ -428,6 +431,10 @@ int dm_plan_destroy(void* plan);
  * Launched before a kernel under test with a NaN bit pattern, it turns any read of LDS bytes that kernel did not write itself into
  * NaNs in an exact-integer result.  Not used by the product path.                                                               */
 int dm_debug_poison_lds(uint32_t pattern, dm_stream_t stream);
+
+/* Zero many float ranges in one launch: table[e] = {pointer, count} (int64 pairs on the device, count in floats, pointers 16-byte aligned,
+ * counts multiples of 4) — FusedAdamW.zero_grad for the gradient ranges no overwriting weight-gradient launch will write (r04). */
+int dm_zero_ranges(const int64_t* table_dev, int n_entries, dm_stream_t stream);
 
 /* ---- data-parallel collective (allreduce_bucket(ptr, n, dtype, comm, stream)) -----------------------------
  * The reference has no distributed code; what the collective must preserve is its gradient accumulation (new_scripy.py:786,

@@ -861,3 +861,55 @@ def test_two_backward_passes_over_one_graph_match_or_fail_loudly():
     worst = max(((g2[k] - 2 * g1[k]).norm() / (2 * g1[k].norm() + 1e-20)).item() for k in g1 if g1[k].norm() > 1e-6)
     print("two backward passes: worst relative deviation from 2 x one pass", worst)
     assert worst <= 2e-3, worst
+
+
+def test_lazy_zero_grad_overwriting_weight_gradients_match_the_full_fill():
+    """r04: FusedAdamW.zero_grad leaves the gradient ranges of the layers on the halo weight-gradient kernel un-zeroed (marked fresh; their
+    first launch overwrites: DmWgrad.overwrite -> the reduce launch writes instead of read-modify-writing) and zeroes the rest with one
+    dm_zero_ranges launch.  Against the same model with the full fill (`_lazy_enabled = False`): per-step loss and pre-clip gradient
+    norm over four steps incl. a two-micro-batch accumulation group; a fresh range nobody wrote is zeros after settle_fresh()."""
+    import diffusionmodel_amd as D
+
+    def make(lazy):
+        torch.manual_seed(21)
+        net = D.ContextUnet(3, 64, 4, bottleneck_k=4, dtype=torch.bfloat16)
+        ddpm = D.DDPM(net, (1e-4, 0.02), 1, DEV, drop_prob=0.0)
+        ddpm.train()
+        ddpm.rng_seed = 5
+        opt = D.FusedAdamW(ddpm.parameters(), lr=1e-3, weight_decay=1e-5, max_grad_norm=1.0)
+        opt._lazy_enabled = lazy
+        return ddpm, opt
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(4, 3, 64, 64, generator=g).to(DEV)
+    c = torch.randint(0, 4, (4,), generator=g).to(DEV)
+    am = torch.ones(4, 64, 64).to(DEV)
+
+    def run(lazy):
+        ddpm, opt = make(lazy)
+        rec = []
+        for step in range(4):
+            opt.zero_grad()
+            n_micro = 2 if step == 2 else 1                     # one accumulation group: the second micro-batch must ADD
+            for m in range(n_micro):
+                loss = ddpm(x[m::n_micro], c[m::n_micro], am[m::n_micro]) / n_micro
+                loss.backward()
+            opt.step()
+            rec.append((loss.item(), opt.grad_norm().item()))
+        return rec, ddpm, opt
+
+    ra, da, oa = run(False)
+    rb, db, ob = run(True)
+    assert oa._lazy is None and ob._lazy is not None
+    table, n_rows, lazy = ob._lazy
+    lazy_elems = sum(p.numel() for p in lazy)
+    assert len(lazy) >= 20 and lazy_elems > 0.5 * ob.total, (len(lazy), lazy_elems, ob.total)      # the 3x3 layers: most of the buffer
+    for (la, na), (lb, nb) in zip(ra, rb):
+        assert abs(la - lb) <= 2e-3 * max(abs(la), 1e-3), (ra, rb)
+        assert abs(na - nb) <= 2e-2 * na, (ra, rb)
+    # a fresh range that no launch writes: garbage until settle_fresh(), zeros after (what an idle data-parallel rank contributes)
+    ob.zero_grad()
+    lazy[0].main_grad.fill_(7.0)
+    assert lazy[0]._dm_fresh
+    ob.settle_fresh()
+    assert float(lazy[0].main_grad.abs().max()) == 0.0 and not lazy[0]._dm_fresh

@@ -539,3 +539,21 @@ def test_create_loaders_is_the_reference_split_and_shards_by_rank():
         parts.append([[int(v) for v in b[0].reshape(-1)] for b in t2])
     assert len(parts[0]) == 3 and len(parts[1]) == 2                                                     # 40 samples -> 5 micro-batches
     assert sorted(v for p_ in parts for b in p_ for v in b) == sorted(int(i) for i in tr_ref)
+
+
+def test_wait_ranks_terminates_the_siblings_of_a_rank_that_died():
+    """parallel.launch_ranks / bench.py's launcher waited for the ranks one after the other, so when one died the
+    survivors sat in their collectives until the RCCL timeout.  wait_ranks polls all children and terminates the rest on the first
+    non-zero exit."""
+    import subprocess
+    import sys
+    import time
+    from diffusionmodel_amd.parallel import wait_ranks
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, "-c", "import time; time.sleep(120)"]),
+             subprocess.Popen([sys.executable, "-c", "import sys, time; time.sleep(0.5); sys.exit(3)"])]
+    codes = wait_ranks(procs)
+    assert time.time() - t0 < 30, "the surviving rank was not terminated"
+    assert codes[1] == 3 and codes[0] not in (0, None)
+    procs = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(2)]
+    assert wait_ranks(procs) == [0, 0]
