@@ -491,8 +491,10 @@ def test_train_engine_plan_then_eager_tail_batch_starts_from_a_zero_gradient():
     assert ob._step == oa._step == 5 and int(ob._step_dev.item()) == 5
     for i, ((la, na), (lb, nb)) in enumerate(zip(ra, rb)):
         # through the step after the tail the two runs agree to the atomics band; after five lr = 1e-3 Adam steps on B = 2 they drift (1e-3)
-        assert abs(la - lb) <= (2e-4 if i <= 3 else 5e-3) * max(abs(la), 1e-3), (ra, rb)
-        assert abs(na - nb) <= (2e-2 if i <= 3 else 0.1) * na, (ra, rb)              # (the stale gradient makes the tail step's norm ~2x; Adam steps on atomics-ordered sums drift by ~5e-3)
+        # (run-to-run band of this B = 2 / B = 1 trajectory, measured over the round's runs: the tail step's norm 1.7185 .. 1.7496 for the SAME
+        #  engine — fp32 atomics through lr = 1e-3 Adam steps; the stale gradient of the bug doubles it)
+        assert abs(la - lb) <= (2e-4 if i <= 2 else 5e-3) * max(abs(la), 1e-3), (ra, rb)
+        assert abs(na - nb) <= (5e-2 if i <= 3 else 0.15) * na, (ra, rb)              # (the stale gradient makes the tail step's norm ~2x; Adam steps on atomics-ordered sums drift by ~5e-3)
     rel = ((oa.flat_p - ob.flat_p).norm() / oa.flat_p.norm()).item()
     assert rel < 5e-3, rel
 
