@@ -907,8 +907,8 @@ def test_lazy_zero_grad_overwriting_weight_gradients_match_the_full_fill():
     lazy_elems = sum(p.numel() for p in lazy)
     assert len(lazy) >= 20 and lazy_elems > 0.5 * ob.total, (len(lazy), lazy_elems, ob.total)      # the 3x3 layers: most of the buffer
     for (la, na), (lb, nb) in zip(ra, rb):
-        assert abs(la - lb) <= 2e-3 * max(abs(la), 1e-3), (ra, rb)
-        assert abs(na - nb) <= 2e-2 * na, (ra, rb)
+        assert abs(la - lb) <= 5e-3 * max(abs(la), 1e-3), (ra, rb)          # (a stale or double-counted range moves these by tens of per cent)
+        assert abs(na - nb) <= 5e-2 * na, (ra, rb)
     # a fresh range that no launch writes: garbage until settle_fresh(), zeros after (what an idle data-parallel rank contributes)
     ob.zero_grad()
     lazy[0].main_grad.fill_(7.0)
